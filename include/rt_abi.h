@@ -1,0 +1,143 @@
+/* rt_abi.h — C ABI of the MI355X render loop (librt_hip.so).
+ *
+ * This is the drop-in boundary for the reference's `Scene.renderScene : unit -> unit`
+ * (raytracer/Scene.fs:117-121).  The reference has no FFI of its own; the seam is the
+ * set of values renderScene closes over and the three buffers it fills:
+ *
+ *   inputs   surfaces           raytracer/Scene.fs:33   (Surface array, SceneDefinitions.fs:119)
+ *            cameraWS, lookAt   raytracer/Scene.fs:36-41
+ *            fov                raytracer/Scene.fs:43
+ *            width,height,spp   raytracer/Scene.fs:18-20
+ *            maxTraceDepth      raytracer/Scene.fs:31
+ *            backgroundColor    raytracer/Scene.fs:32
+ *   outputs  frameBuffer        raytracer/Scene.fs:28   Vector4[width,height]  -> rgba
+ *            depthBuffer        raytracer/Scene.fs:29   float32[width,height]  -> depth
+ *            maxFrameBufferDepth raytracer/Scene.fs:30                          -> max_depth
+ *
+ * All structs are blittable (an F# host passes them with [<DllImport>]).
+ * Vector3 = 3 packed f32, Matrix4x4 = 16 f32 row-major M11..M44 (System.Numerics layout).
+ * Buffers are indexed like `Array2D.create width height` (Scene.fs:28): linear = px*height + py.
+ *
+ * Conventions: every entry point returns 0 on success and a negative RT_E_* code on failure,
+ * never throws across the boundary; rt_last_error() returns a thread-local message.
+ * There is NO CPU fallback in this library: without a HIP device every call fails with RT_E_NO_DEVICE.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------ */
+#define RT_OK              0
+#define RT_E_INVALID      -1   /* bad argument (null pointer, size, enum value)              */
+#define RT_E_NO_DEVICE    -2   /* no HIP device / device index out of range                  */
+#define RT_E_HIP          -3   /* a HIP runtime call failed (message has the HIP error)      */
+#define RT_E_OVERFLOW     -4   /* the in-LDS ray pool overflowed its proven bound (a bug)    */
+#define RT_E_UNSUPPORTED  -5   /* valid request this build does not implement                */
+
+/* ---- surface kinds: the Surface subclasses of raytracer/Surface.fs ---------------------- */
+#define RT_KIND_NOSURFACE  0   /* Surface.fs:44-47   0 samples, radiance = Emitted           */
+#define RT_KIND_LAMBERTIAN 1   /* Surface.fs:60-83   SampleCount 4 (overridable)             */
+#define RT_KIND_METAL      2   /* Surface.fs:85-109  SampleCount 1                           */
+#define RT_KIND_DIELECTRIC 3   /* Surface.fs:112-181 1 or 2 deterministic samples            */
+
+/* ---- geometry kinds: the Hitable subclasses of raytracer/Geometry ----------------------- */
+#define RT_GEOM_SPHERE     0   /* Geometry/Sphere.fs:8                                       */
+#define RT_GEOM_PLANE      1   /* Geometry/Plane.fs:12                                       */
+#define RT_GEOM_TRIANGLE   2   /* not in the reference (Geometry/AABB.fs is empty); obeys the
+                                  Hitable contract of Geometry/Core.fs:26-43                 */
+
+/* One `Surface` (Surface.fs:15) flattened: kind + material (Material.fs:9-18) + geometry.
+ *   g[] for RT_GEOM_SPHERE  : center.xyz, radius                       (Sphere.fs:8)
+ *   g[] for RT_GEOM_PLANE   : normal.xyz, d, has_center(0/1), center.xyz, width, height
+ *                             (System.Numerics.Plane + the three options of Plane.fs:12)
+ *   g[] for RT_GEOM_TRIANGLE: v0.xyz, v1.xyz, v2.xyz
+ * sample_count: 0 = the kind's default (NoSurface 0, Lambertian rt_params.lambertian_samples,
+ *   Metal 1); 1..4 overrides `SampleCount` (Surface.fs:20) for Lambertian and Metal. Ignored
+ *   for Dielectric, whose GenerateSamples override fixes 1 or 2 (Surface.fs:168-181).        */
+typedef struct rt_surface {
+    int32_t  kind;
+    int32_t  geom;
+    uint64_t id;            /* Surface.ID (Surface.fs:10,25); 0 is reserved for "miss"        */
+    float    albedo[3];     /* Material.Albedo                                               */
+    float    emission[3];   /* Material.Emmitance                                            */
+    float    fuzz;          /* Metal      (clamped to [0,1] as Surface.fs:88)                */
+    float    ior;           /* Dielectric refractiveIndex                                    */
+    int32_t  sample_count;
+    float    g[12];
+} rt_surface;
+
+/* Camera state renderScene closes over (Scene.fs:36-43).  cam_to_world is what
+ * `CameraToWorld (WorldToCamera origin lookAt UnitY)` returns (Camera.fs:41-45): the host
+ * computes CreateLookAt + Invert.  look_at is the *target point* the reference normalises and
+ * dots with the primary direction (Scene.fs:37,76).                                           */
+typedef struct rt_camera {
+    float cam_to_world[16];
+    float look_at[3];
+    float fov;              /* radians, Scene.fs:43                                          */
+} rt_camera;
+
+/* Render constants (Scene.fs:18-32) plus what the build adds: the counter-based RNG seed, the
+ * deterministic-pinhole switch and the pixel-column partition used for multi-GPU.
+ * Columns rendered: px = x_begin + k*x_step for k = 0,1,... while px < x_end
+ * (x_begin=0,x_end=width,x_step=1 is the whole frame).  Output buffers are COMPACT over the
+ * rendered columns: element (k, py) lives at k*height + py; with the whole-frame settings
+ * that is exactly px*height + py.                                                            */
+typedef struct rt_params {
+    int32_t  width, height;       /* Scene.fs:18-19                                          */
+    int32_t  spp;                 /* samplesPerPixel, Scene.fs:20                             */
+    int32_t  max_trace_depth;     /* maxTraceDepth,  Scene.fs:31  (0..28)                     */
+    float    background[3];       /* backgroundColor, Scene.fs:32                             */
+    int32_t  jitter;              /* 0 = deterministic pinhole (pertrube offset 0), 1 = on    */
+    uint64_t seed;                /* Philox4x32-10 key                                        */
+    int32_t  lambertian_samples;  /* Lambertian SampleCount; 0 = 4 (Surface.fs:63); 1..4      */
+    int32_t  x_begin, x_end, x_step;
+    int32_t  slots_per_wave;      /* tuning: pixel-samples one wave traces together; 0 = auto */
+} rt_params;
+
+typedef struct rt_scene rt_scene;   /* opaque: device-resident SoA scene + workspace          */
+
+/* Replaces `scene_spheres |> Array.ofList` (Scene.fs:33): flattens the surfaces to SoA,
+ * precomputes the per-plane rectangle constants of Plane.fs:19-30 in the reference's f32
+ * operation order, and uploads everything once to the HBM of `device`.                        */
+int  rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_scene** out);
+
+/* Replaces `Scene.renderScene ()` (Scene.fs:117-121).  Synchronous; host output buffers.
+ * rgba  [ncols*height*4]  Vector4(sqrt(avg),1)            (Scene.fs:114)
+ * depth [ncols*height]    t of the first sample's primary hit, FLT_MAX on a miss (Scene.fs:29,80)
+ * object_id [ncols*height] Surface.ID of that hit, 0 on a miss; may be NULL
+ * max_depth               maxFrameBufferDepth over the rendered columns (Scene.fs:47-48); may be NULL
+ * ray_count               number of findClosestIntersection invocations (Surface.fs:49); may be NULL */
+int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+               float* rgba, float* depth, uint64_t* object_id,
+               float* max_depth, uint64_t* ray_count);
+
+/* Same render, but asynchronous on `stream` (a hipStream_t; NULL = default stream) with DEVICE
+ * output buffers, so a caller that owns device memory (torch, RCCL gather of the framebuffer)
+ * never crosses PCIe.  d_stats points at 2 device u64: [0] ray count, [1] bit pattern of
+ * max depth (f32) in the low word; may be NULL.  No counterpart in the reference.             */
+int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                      void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
+                      uint64_t* d_stats);
+
+/* After a render on `scene` has completed: 0, or RT_E_OVERFLOW if any wave's ray pool
+ * overflowed (results are then invalid).  rt_render checks this itself.                       */
+int  rt_scene_status(rt_scene* scene);
+
+void rt_scene_destroy(rt_scene* scene);
+
+/* Thread-local text of the last error on this thread ("" if none). Never NULL.               */
+const char* rt_last_error(void);
+
+/* ABI version: bumped whenever a struct layout or signature changes.                         */
+int  rt_abi_version(void);
+#define RT_ABI_VERSION 1
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of oracle/librt_oracle.so — the CPU checker.  Test infrastructure only:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import abi, host
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(_ROOT, "oracle")
+ORACLE_PATH = os.path.join(ORACLE_DIR, "librt_oracle.so")
+
+FLAG_LITERAL_PLANE = 1
+FLAG_LITERAL_LEAVES = 2
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(ORACLE_PATH):
+        build()
+    lib = C.CDLL(ORACLE_PATH)
+    P = C.POINTER
+    lib.rto_render.argtypes = [P(abi.rt_surface), C.c_int64, P(abi.rt_camera), P(abi.rt_params), C.c_uint, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_float), P(C.c_uint64)]
+    lib.rto_render.restype = C.c_int
+    lib.rto_round.argtypes = [C.c_float, C.c_int]
+    lib.rto_round.restype = C.c_float
+    lib.rto_pow5.argtypes = [C.c_float]
+    lib.rto_pow5.restype = C.c_float
+    lib.rto_philox4x32_10.argtypes = [P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
+    lib.rto_sincos_2pi.argtypes = [C.c_float, P(C.c_float), P(C.c_float)]
+    lib.rto_intersect.argtypes = [P(abi.rt_surface), P(C.c_float), P(C.c_float), C.c_float,
+                                  P(C.c_int), P(C.c_float), P(C.c_int)]
+    lib.rto_generate_samples.argtypes = [P(abi.rt_surface), P(C.c_float), P(C.c_float), C.c_float,
+                                         C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_float)]
+    lib.rto_generate_samples.restype = C.c_int
+    lib.rto_hemisphere_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_float)]
+    lib.rto_unit_sphere_sample.argtypes = [C.c_uint64, C.c_uint64, P(C.c_float)]
+    lib.rto_frame_around.argtypes = [P(C.c_float), P(C.c_float), P(C.c_float)]
+    lib.rto_plane_rotation.argtypes = [P(C.c_float), P(C.c_float)]
+    lib.rto_create_look_at.argtypes = [P(C.c_float)] * 4
+    lib.rto_invert.argtypes = [P(C.c_float), P(C.c_float)]
+    lib.rto_invert.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def render(surfaces, cam, params, flags=0, nthreads=0):
+    """Oracle render. Returns dict(rgba[ncols,H,4], depth[ncols,H], ids[ncols,H], max_depth, rays)."""
+    lib = load()
+    arr = host.flatten_surfaces(surfaces) if isinstance(surfaces, (list, tuple)) else surfaces
+    n = len(surfaces)
+    ncols, H = host.num_columns(params), params.height
+    rgba = np.empty((ncols, H, 4), dtype=np.float32)
+    depth = np.empty((ncols, H), dtype=np.float32)
+    ids = np.empty((ncols, H), dtype=np.uint64)
+    md, rc = C.c_float(0), C.c_uint64(0)
+    r = lib.rto_render(arr, n, C.byref(cam), C.byref(params), flags, nthreads,
+                       rgba.ctypes.data, depth.ctypes.data, ids.ctypes.data, C.byref(md), C.byref(rc))
+    if r != 0:
+        raise RuntimeError(f"rto_render failed: {r}")
+    return dict(rgba=rgba, depth=depth, ids=ids, max_depth=md.value, rays=rc.value)
