@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the render loop on N MI355X (one process per GPU).
+
+A "step" is one full frame of the workload: every rank renders its interleaved image columns with
+the HIP kernel (device buffers, no PCIe in the timed region), the framebuffer and depth buffer are
+gathered to rank 0 over RCCL/xGMI, and ray count / max depth are all-reduced.  The frame is fixed
+as N grows (strong scaling): value = rays of the whole frame / max-over-ranks time.
+
+A ray = one findClosestIntersection query (Surface.fs:49): primary + every bounce ray intersected.
+
+Workloads (BASELINE.json configs; scene = SceneDefinitions.scene_spheres, camera of Scene.fs:36-43):
+  c4s  3840x2160, 64 spp, maxTraceDepth 5, jitter on  — the "4K 64spp" of the metric (default)
+  c2   800x640, 16 spp, maxTraceDepth 4, jitter on    — configs[1]
+  c1   640x480, 1 spp, maxTraceDepth 5, pinhole       — configs[0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+WORKLOADS = {
+    "c4s": dict(width=3840, height=2160, samplesPerPixel=64, maxTraceDepth=5, jitter=1, seed=1),
+    "c2": dict(width=800, height=640, samplesPerPixel=16, maxTraceDepth=4, jitter=1, seed=1),
+    "c1": dict(width=640, height=480, samplesPerPixel=1, maxTraceDepth=5, jitter=0, seed=1),
+}
+
+# Algorithmic FP32 work per ray, counted from the reference's F# (SURVEY.md section 8(d)); sqrt and
+# divide count 1.  Closest hit on scene_spheres = 6 sphere tests (27) + 6 plane tests (13) + 5
+# rectangle tests (25) + 12 PointForRay (6) = 437 flops per ray.  Ray generation ("shade") adds
+# ~90 flops per Lambertian child, 60 per Metal child, 110 per Dielectric child, 30 per primary; the
+# kernel does not count children by kind, so the bench prices every ray at 437 + 60 (a lower bound
+# for this scene, where most children are Lambertian).
+FLOPS_PER_RAY = 437.0 + 60.0
+VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def cpu_baseline():
+    """The oracle ("port" of the reference's F# loop) on the host cores of this box, config c1."""
+    import oracle_lib as O
+    from raytracer_amd import host
+
+    cam = host.make_camera()
+    w = WORKLOADS["c1"]
+    p = host.make_params(w["width"], w["height"], w["samplesPerPixel"], w["maxTraceDepth"], jitter=w["jitter"], seed=w["seed"])
+    surfaces = host.SceneDefinitions.scene_spheres
+    O.render(surfaces, cam, host.make_params(64, 48, 1, 5, jitter=0), nthreads=1)     # load + warm
+    t0 = time.perf_counter()
+    r = O.render(surfaces, cam, p, nthreads=1)
+    t1 = time.perf_counter() - t0
+    ncores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    t0 = time.perf_counter()
+    r2 = O.render(surfaces, cam, p, nthreads=ncores)
+    tn = time.perf_counter() - t0
+    return {
+        "value": r["rays"] / t1 / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+        "sample": "config c1 whole frame: 640x480, 1 spp, maxTraceDepth 5, %d rays, reference-faithful recursion" % r["rays"],
+        "all_cores": {"value": r2["rays"] / tn / 1e6, "cores": ncores},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4s", choices=sorted(WORKLOADS))
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import multi
+    from raytracer_amd.scene import Scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def make(wl):
+        cfg = WORKLOADS[wl]
+        sc = Scene(device=local_rank, slots_per_wave=args.slots, **cfg)
+        xb, xe, xs, ncols = multi.columns_of_rank(sc.width, rank, world)
+        bufs = dict(
+            rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
+            depth=torch.zeros((ncols, sc.height), dtype=torch.float32, device=dev),
+            stats=torch.zeros(2, dtype=torch.int64, device=dev),
+        )
+        g = multi.FrameGatherer(sc.width, sc.height, dev, rank, world)
+        return sc, (xb, xe, xs), bufs, g
+
+    def step(sc, cols, bufs, g, ev=None):
+        stream = torch.cuda.current_stream().cuda_stream
+        if ev:
+            ev[0].record()
+        sc.renderColumnsDevice(bufs["rgba"].data_ptr(), bufs["depth"].data_ptr(), None, bufs["stats"].data_ptr(),
+                               stream, cols[0], cols[1], cols[2])
+        if ev:
+            ev[1].record()
+        st = bufs["stats"].cpu()        # syncs this stream: ray count + max depth bits of this rank
+        rays = int(st[0].item())
+        maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
+        return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
+
+    def run(wl, steps, warmup):
+        sc, cols, bufs, g = make(wl)
+        for _ in range(warmup):
+            step(sc, cols, bufs, g)
+        sc.status()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        rays = 0
+        for i in range(steps):
+            r, _ = step(sc, cols, bufs, g, evs[i])
+            rays += r
+        barrier()
+        dt = time.perf_counter() - t0
+        sc.status()
+        kern_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sc.close()
+        return rays, float(tt.item()), kern_ms, sc
+
+    rays, dt, kern_ms, sc = run(args.workload, args.steps, args.warmup)
+    rays_per_frame = rays / args.steps
+    out = None
+    if rank == 0:
+        cfg = WORKLOADS[args.workload]
+        local_rays = rays_per_frame / world          # interleaved columns: equal shares to <1 %
+        achieved = local_rays * FLOPS_PER_RAY / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s (primary+bounce)", "value": rays / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: scene_spheres (12 surfaces) %dx%d, %d spp, maxTraceDepth %d, jitter %d" % (
+                           args.workload, cfg["width"], cfg["height"], cfg["samplesPerPixel"], cfg["maxTraceDepth"], cfg["jitter"]),
+                       "rays_per_frame": rays_per_frame, "partition": "interleaved columns, %d rank(s), RCCL gather to rank 0" % world},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "rt::render_kernel", "kernel_ms": kern_ms, "flops_per_ray": FLOPS_PER_RAY},
+        }
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+        for wl in ("c1", "c2"):
+            if wl == args.workload:
+                continue
+            r, t, k, _ = run(wl, 20, 3)
+            extra[wl] = {"Mrays_per_s": r / t / 1e6, "ms_per_frame": t / 20 * 1e3, "kernel_ms": k, "rays_per_frame": r / 20}
+        out["extra"] = extra
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,12 @@ int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* pa
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);
 
+/* findClosestIntersection (Surface.fs:49-58) as a batch query over host arrays: for ray i with
+ * origin origins[3i..] and (unit) direction directions[3i..], index[i] = array index of the
+ * closest acceptable surface (-1 = none) and t[i] = its ray parameter (FLT_MAX if none).      */
+int  rt_find_closest(rt_scene* scene, int64_t nrays, const float* origins, const float* directions,
+                     float* t, int32_t* index);
+
 /* After a render on `scene` has completed: 0, or RT_E_OVERFLOW if any wave's ray pool
  * overflowed (results are then invalid).  rt_render checks this itself.                       */
 int  rt_scene_status(rt_scene* scene);

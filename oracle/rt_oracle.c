@@ -713,6 +713,21 @@ void rto_intersect(const rt_surface *a, const float o[3], const float d[3], floa
     geom_intersect(&s, &r, has, t);
     *acceptable = geom_acceptable(&s, *has, *t, dot_view, point_for_ray(&r, *t), 0);
 }
+/* findClosestIntersection (Surface.fs:49-58) over a whole surface array, for a batch of rays */
+void rto_find_closest(const rt_surface *surfaces, int64_t n, int64_t nrays, const float *o, const float *d,
+                      float *t_out, int32_t *idx_out)
+{
+    osurf *surf = (osurf *)malloc(sizeof(osurf) * (size_t)(n > 0 ? n : 1));
+    convert_surfaces(surfaces, n, 4, surf);
+    octx c; memset(&c, 0, sizeof c); c.surf = surf; c.n = (int)n;
+    for (int64_t i = 0; i < nrays; i++) {
+        ray_t r; r.o = V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.d = V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        int b; float t;
+        idx_out[i] = find_closest_intersection(&c, &r, &b, &t);
+        t_out[i] = t;
+    }
+    free(surf);
+}
 /* Surface.GenerateSamples for one surface hit at parameter t */
 int rto_generate_samples(const rt_surface *a, const float o[3], const float d[3], float t,
                          uint64_t seed, uint64_t ps, uint64_t node, float out_dirs[12], float out_shading[12])

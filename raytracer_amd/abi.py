@@ -87,6 +87,7 @@ ABI_SYMBOLS = (
     "rt_scene_create",
     "rt_render",
     "rt_render_device",
+    "rt_find_closest",
     "rt_scene_status",
     "rt_scene_destroy",
     "rt_last_error",
@@ -116,6 +117,8 @@ def load_hip_library():
     lib.rt_render_device.argtypes = [C.c_void_p, P(rt_camera), P(rt_params), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rt_render_device.restype = C.c_int
+    lib.rt_find_closest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rt_find_closest.restype = C.c_int
     lib.rt_scene_status.argtypes = [C.c_void_p]
     lib.rt_scene_status.restype = C.c_int
     lib.rt_scene_destroy.argtypes = [C.c_void_p]

@@ -1,0 +1,211 @@
+// rt_device.h — device-side numerics and scene layout of the MI355X render loop.
+//
+// Every arithmetic step is a single IEEE f32 operation in the order System.Numerics performs it
+// (DESIGN.md "Numerics contract"); the translation unit is compiled with -ffp-contract=off and
+// hipcc's default correctly rounded f32 divide/sqrt, so a ray computed here has bit-identical
+// t / hit point / child direction to the CPU restatement in oracle/ (which is NOT included or
+// linked: this file is an independent implementation of the same reference lines).
+//
+// Reference lines are relative to /root/reference/raytracer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+constexpr float kTMin = 0.001f;   // Geometry/Core.fs:37
+constexpr float kTMax = 500.0f;   // Geometry/Core.fs:38
+constexpr float kFltMax = 3.402823466e+38f;
+
+// geometry types of the flattened scene (bounded and unbounded planes are split so the
+// closest-hit loop branches on a wave-uniform scalar)
+constexpr int kGeomSphere = 0, kGeomPlaneInf = 1, kGeomPlaneRect = 2;
+// surface kinds == RT_KIND_*
+constexpr int kKindNone = 0, kKindLambert = 1, kKindMetal = 2, kKindDielectric = 3;
+
+// One surface's geometry, read with SCALAR loads (the loop index is wave-uniform).  80 bytes.
+//   sphere : a = center.xyz, radius^2                                  (Sphere.fs:18-27)
+//   plane  : a = plane.Normal (as stored).xyz, plane.D                  (Plane.fs:36-40)
+//   rect   : b = first column of R (R11,R21,R31),  x upper bound  (newB.x + w/2)
+//            c = second column of R (R12,R22,R32), x lower bound  (newB.x - w/2)
+//            d = kern.xyz,                          y upper bound  (newB.y + h/2)
+//            ymin =                                 y lower bound  (newB.y - h/2)   (Plane.fs:19-34)
+struct alignas(16) GeomRec {
+    float a[4], b[4], c[4], d[4];
+    float ymin;
+    int32_t type;
+    int32_t pad[2];
+};
+static_assert(sizeof(GeomRec) == 80, "GeomRec layout");
+
+// One surface's shading data, gathered per lane by hit index.  64 bytes = four 16-byte loads.
+struct alignas(16) ShadeRec {
+    float albedo[3];      // Material.Albedo
+    float param;          // Metal: clamp(fuzz,0,1) (Surface.fs:88); Dielectric: refractive index
+    float emission[3];    // Material.Emmitance
+    uint32_t info;        // kind | nsamples << 2 | geom << 5
+    float nc[3];          // sphere: center; plane: Normalize(plane.Normal) (Plane.fs:15)
+    uint32_t pad0;
+    uint64_t id;          // Surface.ID
+    uint64_t pad1;
+};
+static_assert(sizeof(ShadeRec) == 64, "ShadeRec layout");
+
+struct f3 { float x, y, z; };
+
+#define RT_DEV __device__ __forceinline__
+
+RT_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+RT_DEV f3 neg(f3 a) { return F3(-a.x, -a.y, -a.z); }
+// Vector3.Dot: (x*x' + y*y') + z*z'
+RT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// Vector3 / float : one reciprocal, three multiplies
+RT_DEV f3 divs(f3 a, float s) { float inv = 1.0f / s; return F3(a.x * inv, a.y * inv, a.z * inv); }
+RT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+RT_DEV f3 normalize(f3 a) { return divs(a, length(a)); }
+
+// Numerics.fs:9  MathF.Round(x, digits) with p = 10^digits, midpoint to even
+RT_DEV float round_digits(float x, float p)
+{
+    if (fabsf(x) < 1e8f) { x = x * p; x = rintf(x); x = x / p; }
+    return x;
+}
+// Numerics.fs:12-16 via the Ray constructor, Geometry/Core.fs:21
+RT_DEV f3 normalized_or_fail(f3 v)
+{
+    float len = length(v);
+    if (round_digits(len, 1e5f) == 1.0f) return v;
+    return divs(v, len);
+}
+
+// ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter =
+//      (pixel-sample index, ray-tree node index); replaces Henzai.Core RandomSampling.
+RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+RT_DEV float u01(uint32_t w) { return (float)(w >> 8) * 0x1p-24f; }
+
+// sin/cos of 2*pi*u, u in [0,1): exact octant reduction + degree-7/8 minimax polynomials on
+// [-pi/4, pi/4]; each line is one f32 rounding so CPU and GPU agree bit for bit.
+RT_DEV void sincos_2pi(float u, float& s_out, float& c_out)
+{
+    float t = u * 8.0f;
+    int k = (int)t;
+    int j = (k + 1) & ~1;
+    float f = t - (float)j;
+    float a = f * 0.78539816339744830962f;
+    float z = a * a;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * a + a;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.0f;
+    int q = (j >> 1) & 3;
+    float s = (q & 1) ? cp : sp;
+    float c = (q & 1) ? sp : cp;
+    s_out = (q & 2) ? -s : s;
+    c_out = (q == 1 || q == 2) ? -c : c;
+}
+
+// RandomSampling.RandomInUnitHemisphere (call sites Surface.fs:72,99): uniform on the y-up
+// hemisphere, .Y = cos(theta) (Surface.fs:73)
+RT_DEV f3 hemisphere_sample(uint32_t seed_lo, uint32_t seed_hi, uint64_t ps, uint64_t node)
+{
+    uint32_t w0, w1, w2, w3;
+    philox4x32_10((uint32_t)ps, (uint32_t)(ps >> 32), (uint32_t)node, (uint32_t)(node >> 32), seed_lo, seed_hi,
+                  w0, w1, w2, w3);
+    float r1 = u01(w0), r2 = u01(w1);
+    float sin_theta = sqrtf(1.0f - r1 * r1);
+    float s, c;
+    sincos_2pi(r2, s, c);
+    return F3(sin_theta * c, r1, sin_theta * s);
+}
+// RandomSampling.RandomInUnitSphere (call site Camera.fs:9): rejection sampling keyed by
+// (pixel, attempt); at most 32 attempts
+RT_DEV f3 unit_sphere_sample(uint32_t seed_lo, uint32_t seed_hi, uint64_t pixel)
+{
+    for (uint32_t attempt = 0; attempt < 32; attempt++) {
+        uint32_t w0, w1, w2, w3;
+        philox4x32_10((uint32_t)pixel, (uint32_t)(pixel >> 32), attempt, 0xFFFFFFFFu, seed_lo, seed_hi, w0, w1, w2, w3);
+        f3 p = F3(2.0f * u01(w0) - 1.0f, 2.0f * u01(w1) - 1.0f, 2.0f * u01(w2) - 1.0f);
+        if (dot(p, p) < 1.0f) return p;
+    }
+    return F3(0.0f, 0.0f, 0.0f);
+}
+// Geometry.CreateCoordinateSystemAroundNormal (call sites Surface.fs:76,102)
+RT_DEV void frame_around(f3 n, f3& nt, f3& nb)
+{
+    bool xbig = fabsf(n.x) > fabsf(n.y);
+    f3 a = xbig ? F3(n.z, 0.0f, -n.x) : F3(0.0f, -n.z, n.y);
+    float l2 = xbig ? (n.x * n.x + n.z * n.z) : (n.y * n.y + n.z * n.z);
+    nt = divs(a, sqrtf(l2));
+    nb = cross(n, nt);
+}
+
+// ---- closest hit --------------------------------------------------------------------------
+// findClosestIntersection (Surface.fs:49-58): linear scan in array order, strict '<' so the first
+// surface wins ties; each candidate passes Hitable.Intersect + IntersectionAcceptable(.., 1.0, P).
+// `geom` is indexed with a wave-uniform i: the compiler turns the reads into s_load_dwordx4/x8
+// and the operands stay in SGPRs.
+RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D, int& idx_out, float& t_out)
+{
+    int idx = -1;
+    float tmin = kFltMax;
+    for (int i = 0; i < nsurf; i++) {
+        const GeomRec* g = geom + i;
+        const int type = g->type;
+        float t; bool ok;
+        if (type == kGeomSphere) {
+            // Sphere.fs:18-36,42-43
+            f3 ctr = O - F3(g->a[0], g->a[1], g->a[2]);
+            float B = 2.0f * dot(ctr, D);
+            float C = dot(ctr, ctr) - g->a[3];
+            float disc = B * B - 4.0f * C;
+            bool has = !(disc < 0.0f) && !(round_digits(disc, 1e3f) == 0.0f);
+            float sq = sqrtf(disc);
+            float i1 = (-B + sq) / 2.0f, i2 = (-B - sq) / 2.0f;
+            t = (i1 >= kTMin && i2 >= kTMin) ? ((i1 < i2) ? i1 : i2) : ((i1 < 0.0f) ? i2 : i1);
+            ok = has && t > kTMin;
+        } else {
+            // Plane.fs:36-40,45-49
+            f3 N = F3(g->a[0], g->a[1], g->a[2]);
+            float num = -g->a[3] - dot(N, O);
+            float den = dot(N, D);
+            bool has = !(fabsf(den) < kTMin);
+            t = num / den;
+            ok = has && t > kTMin && t <= (kTMax / 1.0f);
+            if (type == kGeomPlaneRect) {
+                // Plane.fs:19-34 with the per-plane constants hoisted
+                f3 P = O + D * t;                                    // Core.fs:59
+                f3 kern = F3(g->d[0], g->d[1], g->d[2]);
+                f3 v = P - kern;
+                float nx = kern.x + (((v.x * g->b[0] + v.y * g->b[1]) + v.z * g->b[2]) + 0.0f);
+                float ny = kern.y + (((v.x * g->c[0] + v.y * g->c[1]) + v.z * g->c[2]) + 0.0f);
+                ok = ok && nx <= g->b[3] && nx >= g->c[3] && ny <= g->d[3] && ny >= g->ymin;
+            }
+        }
+        if (ok && t < tmin) { tmin = t; idx = i; }
+    }
+    idx_out = idx; t_out = tmin;
+}
+
+// MathF.Pow(x, 5) as the oracle states it: x^5 in double, rounded once
+RT_DEV float pow5(float x) { double d = (double)x; double d2 = d * d; return (float)(d2 * d2 * d); }
+
+RT_DEV f3 reflect(f3 d, f3 n) { return d - n * (2.0f * dot(d, n)); }
+
+}  // namespace rt

@@ -1,0 +1,400 @@
+// rt_hip.hip — librt_hip.so: the C ABI of include/rt_abi.h over the HIP render kernel.
+//
+// Host side of the boundary that replaces Scene.renderScene (raytracer/Scene.fs:117-121): scene
+// flattening (Scene.fs:33 `scene_spheres |> Array.ofList`), the per-plane constants of
+// Plane.PointLiesInRectangle (Geometry/Plane.fs:19-30) hoisted out of the per-ray test, camera
+// constants (Camera.fs:20-45, Scene.fs:100-102), launch geometry.  No CPU rendering path exists
+// in this library: without a HIP device every entry point returns RT_E_NO_DEVICE.
+#include "rt_kernels.h"
+
+#include "../../include/rt_abi.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace rt;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(RT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// ---- System.Numerics on the host, float32, one rounding per operation ----------------------
+struct H3 { float x, y, z; };
+inline float hdot(H3 a, H3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+inline H3 hdivs(H3 a, float s) { float inv = 1.0f / s; return { a.x * inv, a.y * inv, a.z * inv }; }
+inline H3 hnormalize(H3 a) { return hdivs(a, sqrtf(hdot(a, a))); }
+
+struct M4 { float m[4][4]; };
+inline M4 mzero() { M4 r; memset(&r, 0, sizeof r); return r; }
+inline M4 mmul(const M4& a, const M4& b)
+{
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r.m[i][j] = ((a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j]) + a.m[i][3] * b.m[3][j];
+    return r;
+}
+// Numerics.fs:51-55,59,63-76: R = I + [w]x + [w]x^2 * (1/(1+cos|w|)), w = a x b  (as written)
+M4 rotation_between_unit_vectors(H3 a, H3 b)
+{
+    H3 w = hcross(a, b);
+    M4 wx = mzero();
+    wx.m[0][1] = -w.z; wx.m[0][2] = w.y;
+    wx.m[1][0] = w.z;  wx.m[1][2] = -w.x;
+    wx.m[2][0] = -w.y; wx.m[2][1] = w.x;
+    M4 wx2 = mmul(wx, wx);
+    float s = 1.0f / (1.0f + cosf(sqrtf(hdot(w, w))));
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r.m[i][j] = (((i == j) ? 1.0f : 0.0f) + wx.m[i][j]) + wx2.m[i][j] * s;
+    return r;
+}
+// Vector4.Transform(Vector4(v, 0), M).xyz
+inline H3 transform_w0(H3 v, const M4& M)
+{
+    return { ((v.x * M.m[0][0] + v.y * M.m[1][0]) + v.z * M.m[2][0]) + 0.0f * M.m[3][0],
+             ((v.x * M.m[0][1] + v.y * M.m[1][1]) + v.z * M.m[2][1]) + 0.0f * M.m[3][1],
+             ((v.x * M.m[0][2] + v.y * M.m[1][2]) + v.z * M.m[2][2]) + 0.0f * M.m[3][2] };
+}
+
+int default_samples(int kind, int sample_count, int lambertian_default)
+{
+    switch (kind) {
+    case RT_KIND_LAMBERTIAN: return sample_count > 0 ? sample_count : lambertian_default;
+    case RT_KIND_METAL:      return sample_count > 0 ? sample_count : 1;
+    case RT_KIND_DIELECTRIC: return 2;
+    default:                 return 0;
+    }
+}
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    int64_t n = 0;
+    GeomRec* d_geom = nullptr;
+    ShadeRec* d_shade[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // index = Lambertian SampleCount default (1..4)
+    int* d_status = nullptr;
+    float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
+    size_t tmp_bytes = 0;
+    std::vector<ShadeRec> h_shade;      // with nsamples of Lambertian-default surfaces left 0
+    std::vector<int> lamb_default;      // surfaces whose Lambertian SampleCount follows rt_params
+};
+
+namespace {
+
+int ensure_tmp(rt_scene* sc, size_t bytes)
+{
+    if (sc->tmp_bytes >= bytes) return RT_OK;
+    if (sc->d_tmp) { HIP_TRY(hipFree(sc->d_tmp)); sc->d_tmp = nullptr; sc->tmp_bytes = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_tmp), bytes));
+    sc->tmp_bytes = bytes;
+    return RT_OK;
+}
+
+// ShadeRec table for one value of the Lambertian SampleCount default (uploaded on first use)
+int shade_table(rt_scene* sc, int lamb, const ShadeRec** out)
+{
+    if (!sc->d_shade[lamb]) {
+        std::vector<ShadeRec> h = sc->h_shade;
+        for (int i : sc->lamb_default) h[i].info |= (uint32_t)lamb << 2;
+        const size_t bytes = sizeof(ShadeRec) * (h.empty() ? 1 : h.size());
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_shade[lamb]), bytes));
+        if (!h.empty()) HIP_TRY(hipMemcpy(sc->d_shade[lamb], h.data(), sizeof(ShadeRec) * h.size(), hipMemcpyHostToDevice));
+    }
+    *out = sc->d_shade[lamb];
+    return RT_OK;
+}
+
+int check_params(const rt_camera* cam, const rt_params* p)
+{
+    if (!cam || !p) return fail(RT_E_INVALID, "null camera or params");
+    if (p->width <= 0 || p->height <= 0 || p->spp <= 0) return fail(RT_E_INVALID, "width, height and spp must be positive");
+    if (p->max_trace_depth < 0 || p->max_trace_depth > 28) return fail(RT_E_INVALID, "max_trace_depth must be in 0..28");
+    if (p->lambertian_samples < 0 || p->lambertian_samples > 4) return fail(RT_E_INVALID, "lambertian_samples must be in 0..4");
+    if (p->x_step <= 0 || p->x_begin < 0 || p->x_end > p->width || p->x_begin > p->x_end)
+        return fail(RT_E_INVALID, "bad column range x_begin/x_end/x_step");
+    if (p->slots_per_wave != 0 && p->slots_per_wave != 64 && p->slots_per_wave != 128 && p->slots_per_wave != 256)
+        return fail(RT_E_INVALID, "slots_per_wave must be 0, 64, 128 or 256");
+    return RT_OK;
+}
+
+template <int S>
+int launch_render(const RenderArgs& a, const GeomRec* geom, const ShadeRec* shade, bool node64, dim3 grid,
+                  size_t smem, hipStream_t stream)
+{
+    if (node64) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<S, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((render_kernel<S, true>), grid, dim3(64), smem, stream, a, geom, shade);
+    } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<S, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((render_kernel<S, false>), grid, dim3(64), smem, stream, a, geom, shade);
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_last_error(void) { return g_err; }
+
+int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_scene** out)
+{
+    if (!out) return fail(RT_E_INVALID, "out is null");
+    *out = nullptr;
+    if (n < 0 || (n > 0 && !surfaces)) return fail(RT_E_INVALID, "bad surface array");
+    if (n > (int64_t)1 << 30) return fail(RT_E_INVALID, "too many surfaces");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_E_NO_DEVICE, "no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RT_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+
+    std::vector<GeomRec> geom((size_t)n);
+    rt_scene* sc = new (std::nothrow) rt_scene;
+    if (!sc) return fail(RT_E_INVALID, "out of host memory");
+    sc->device = device; sc->n = n;
+    sc->h_shade.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        const rt_surface& s = surfaces[i];
+        if (s.kind < 0 || s.kind > 3) { delete sc; return fail(RT_E_INVALID, "surface %lld: bad kind %d", (long long)i, s.kind); }
+        if (s.sample_count < 0 || s.sample_count > 4) { delete sc; return fail(RT_E_INVALID, "surface %lld: sample_count must be 0..4", (long long)i); }
+        GeomRec g; memset(&g, 0, sizeof g);
+        ShadeRec h; memset(&h, 0, sizeof h);
+        for (int c = 0; c < 3; c++) { h.albedo[c] = s.albedo[c]; h.emission[c] = s.emission[c]; }
+        h.id = s.id;
+        if (s.kind == RT_KIND_METAL) h.param = fmaxf(fminf(1.0f, s.fuzz), 0.0f);      // Surface.fs:88
+        else if (s.kind == RT_KIND_DIELECTRIC) h.param = s.ior;
+        int gtype;
+        if (s.geom == RT_GEOM_SPHERE) {
+            gtype = kGeomSphere;
+            g.a[0] = s.g[0]; g.a[1] = s.g[1]; g.a[2] = s.g[2];
+            g.a[3] = s.g[3] * s.g[3];                                                   // Square radius, Sphere.fs:21
+            h.nc[0] = s.g[0]; h.nc[1] = s.g[1]; h.nc[2] = s.g[2];
+        } else if (s.geom == RT_GEOM_PLANE) {
+            const H3 nraw = { s.g[0], s.g[1], s.g[2] };
+            const float d = s.g[3];
+            const H3 pn = hnormalize(nraw);                                             // Plane.fs:15
+            g.a[0] = nraw.x; g.a[1] = nraw.y; g.a[2] = nraw.z; g.a[3] = d;
+            h.nc[0] = pn.x; h.nc[1] = pn.y; h.nc[2] = pn.z;
+            if (s.g[4] != 0.0f) {
+                gtype = kGeomPlaneRect;
+                // Plane.fs:19-30: R, kern and the rotated centre are per-plane constants
+                const M4 R = rotation_between_unit_vectors(pn, H3{ 0.0f, 0.0f, -1.0f });
+                const H3 kern = (d > 0.0f) ? H3{ pn.x * (-1.0f * d), pn.y * (-1.0f * d), pn.z * (-1.0f * d) }
+                                           : H3{ pn.x * d, pn.y * d, pn.z * d };
+                const H3 center = { s.g[5], s.g[6], s.g[7] };
+                const H3 b = { center.x - kern.x, center.y - kern.y, center.z - kern.z };
+                const H3 tb = transform_w0(b, R);
+                const H3 newB = { kern.x + tb.x, kern.y + tb.y, kern.z + tb.z };
+                const float wOff = s.g[8] / 2.0f, hOff = s.g[9] / 2.0f;
+                g.b[0] = R.m[0][0]; g.b[1] = R.m[1][0]; g.b[2] = R.m[2][0]; g.b[3] = newB.x + wOff;
+                g.c[0] = R.m[0][1]; g.c[1] = R.m[1][1]; g.c[2] = R.m[2][1]; g.c[3] = newB.x - wOff;
+                g.d[0] = kern.x; g.d[1] = kern.y; g.d[2] = kern.z; g.d[3] = newB.y + hOff;
+                g.ymin = newB.y - hOff;
+            } else {
+                gtype = kGeomPlaneInf;
+            }
+        } else {
+            delete sc;
+            return fail(s.geom == RT_GEOM_TRIANGLE ? RT_E_UNSUPPORTED : RT_E_INVALID,
+                        "surface %lld: geometry %d is not supported by this build", (long long)i, s.geom);
+        }
+        g.type = gtype;
+        int ns = default_samples(s.kind, s.sample_count, 0);
+        if (s.kind == RT_KIND_LAMBERTIAN && s.sample_count == 0) sc->lamb_default.push_back((int)i);
+        h.info = (uint32_t)s.kind | ((uint32_t)ns << 2) | ((uint32_t)gtype << 5);
+        geom[(size_t)i] = g;
+        sc->h_shade[(size_t)i] = h;
+    }
+
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_geom), sizeof(GeomRec) * (size_t)(n > 0 ? n : 1));
+    if (e == hipSuccess && n > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_status), sizeof(int));
+    if (e == hipSuccess) e = hipMemset(sc->d_status, 0, sizeof(int));
+    if (e != hipSuccess) {
+        rt_scene_destroy(sc);
+        return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
+    }
+    *out = sc;
+    g_err[0] = 0;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* sc)
+{
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    if (sc->d_geom) (void)hipFree(sc->d_geom);
+    for (ShadeRec* p : sc->d_shade) if (p) (void)hipFree(p);
+    if (sc->d_status) (void)hipFree(sc->d_status);
+    if (sc->d_tmp) (void)hipFree(sc->d_tmp);
+    delete sc;
+}
+
+int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, void* stream_v,
+                     float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats)
+{
+    if (!sc) return fail(RT_E_INVALID, "scene is null");
+    int rc = check_params(cam, p);
+    if (rc) return rc;
+    if (!d_rgba || !d_depth) return fail(RT_E_INVALID, "rgba and depth buffers are required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipSetDevice(sc->device));
+
+    const int ncols = (p->x_end - p->x_begin + p->x_step - 1) / p->x_step;
+    if (ncols <= 0) return RT_OK;
+    const int S = p->slots_per_wave ? p->slots_per_wave : 64;
+    const int lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
+    const ShadeRec* shade = nullptr;
+    rc = shade_table(sc, lamb, &shade);
+    if (rc) return rc;
+
+    RenderArgs a; memset(&a, 0, sizeof a);
+    a.rgba = d_rgba; a.depth = d_depth;
+    a.ids = reinterpret_cast<unsigned long long*>(d_object_id);
+    a.stats = reinterpret_cast<unsigned long long*>(d_stats);
+    a.status = sc->d_status;
+    a.nsurf = (int)sc->n; a.W = p->width; a.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
+    a.jitter = p->jitter ? 1 : 0;
+    a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
+    a.x_begin = p->x_begin; a.x_step = p->x_step; a.ncols = ncols;
+    a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
+    for (int c = 0; c < 3; c++) a.bg[c] = p->background[c];
+
+    // pool bound: S level-0 records + 64 per deeper record level (DESIGN.md "Pool bound")
+    a.cap = S + 64 * (p->max_trace_depth + a.bg_nonzero);
+    // pixel tile per wave
+    int G = 1;
+    if (p->spp < S) { while (G * 2 * p->spp <= S) G *= 2; }
+    int gl = 0; while ((1 << gl) < G) gl++;
+    a.tw_log2 = gl / 2; a.th_log2 = gl - gl / 2;
+    a.pix_per_group = G;
+    a.passes = (p->spp > S) ? (p->spp + S - 1) / S : 1;
+    const int tw = 1 << a.tw_log2, th = 1 << a.th_log2;
+    a.ntx = (ncols + tw - 1) / tw;
+    const long long nty = (p->height + th - 1) / th;
+    const long long ngroups = (long long)a.ntx * nty;
+    if (ngroups > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
+
+    // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
+    const float* M = cam->cam_to_world;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.rot[3 * i + j] = M[4 * i + j];
+    a.origin[0] = M[12]; a.origin[1] = M[13]; a.origin[2] = M[14];
+    const H3 ln = hnormalize(H3{ cam->look_at[0], cam->look_at[1], cam->look_at[2] });
+    a.look_n[0] = ln.x; a.look_n[1] = ln.y; a.look_n[2] = ln.z;
+    a.fw = (float)p->width; a.fh = (float)p->height;
+    a.aspect = a.fw / a.fh;
+    a.tan_half = tanf(cam->fov / 2.0f);
+
+    const bool node64 = p->max_trace_depth > 13;
+    const size_t smem = sizeof(uint32_t) * ((size_t)S * 5 + 64 + (size_t)(node64 ? 13 : 12) * a.cap);
+    if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
+
+    HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
+    if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, 2 * sizeof(uint64_t), stream));
+    const dim3 grid((unsigned)ngroups);
+    switch (S) {
+    case 64:  return launch_render<64>(a, sc->d_geom, shade, node64, grid, smem, stream);
+    case 128: return launch_render<128>(a, sc->d_geom, shade, node64, grid, smem, stream);
+    default:  return launch_render<256>(a, sc->d_geom, shade, node64, grid, smem, stream);
+    }
+}
+
+int rt_scene_status(rt_scene* sc)
+{
+    if (!sc) return fail(RT_E_INVALID, "scene is null");
+    HIP_TRY(hipSetDevice(sc->device));
+    int st = 0;
+    HIP_TRY(hipMemcpy(&st, sc->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st) return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its bound; results are invalid");
+    return RT_OK;
+}
+
+int rt_render(rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgba, float* depth, uint64_t* object_id,
+              float* max_depth, uint64_t* ray_count)
+{
+    if (!sc) return fail(RT_E_INVALID, "scene is null");
+    int rc = check_params(cam, p);
+    if (rc) return rc;
+    if (!rgba || !depth) return fail(RT_E_INVALID, "rgba and depth buffers are required");
+    HIP_TRY(hipSetDevice(sc->device));
+    const size_t ncols = (size_t)((p->x_end - p->x_begin + p->x_step - 1) / p->x_step);
+    const size_t npix = ncols * (size_t)p->height;
+    if (npix == 0) { if (max_depth) *max_depth = 0.0f; if (ray_count) *ray_count = 0; return RT_OK; }
+    // staging layout: stats (16 B) | ids (8 B each) | rgba (16 B each) | depth (4 B each)
+    const size_t off_ids = 16, off_rgba = off_ids + npix * 8, off_depth = off_rgba + npix * 16;
+    rc = ensure_tmp(sc, off_depth + npix * 4);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(sc->d_tmp);
+    uint64_t* d_stats = reinterpret_cast<uint64_t*>(base);
+    uint64_t* d_ids = reinterpret_cast<uint64_t*>(base + off_ids);
+    float* d_rgba = reinterpret_cast<float*>(base + off_rgba);
+    float* d_depth = reinterpret_cast<float*>(base + off_depth);
+    rc = rt_render_device(sc, cam, p, nullptr, d_rgba, d_depth, object_id ? d_ids : nullptr, d_stats);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    rc = rt_scene_status(sc);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(rgba, d_rgba, npix * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(depth, d_depth, npix * 4, hipMemcpyDeviceToHost));
+    if (object_id) HIP_TRY(hipMemcpy(object_id, d_ids, npix * 8, hipMemcpyDeviceToHost));
+    uint64_t st[2];
+    HIP_TRY(hipMemcpy(st, d_stats, sizeof st, hipMemcpyDeviceToHost));
+    if (ray_count) *ray_count = st[0];
+    if (max_depth) { uint32_t bits = (uint32_t)st[1]; memcpy(max_depth, &bits, 4); }
+    g_err[0] = 0;
+    return RT_OK;
+}
+
+int rt_find_closest(rt_scene* sc, int64_t nrays, const float* origins, const float* directions, float* t, int32_t* index)
+{
+    if (!sc) return fail(RT_E_INVALID, "scene is null");
+    if (nrays < 0 || (nrays > 0 && (!origins || !directions || !t || !index))) return fail(RT_E_INVALID, "bad ray arrays");
+    if (nrays == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(sc->device));
+    const size_t n = (size_t)nrays;
+    int rc = ensure_tmp(sc, n * 32);
+    if (rc) return rc;
+    float* d_o = sc->d_tmp; float* d_d = d_o + 3 * n; float* d_t = d_d + 3 * n; int* d_i = reinterpret_cast<int*>(d_t + n);
+    HIP_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, directions, n * 12, hipMemcpyHostToDevice));
+    const long long blocks = ((long long)n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(RT_E_INVALID, "too many rays for one launch");
+    hipLaunchKernelGGL(find_closest_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, sc->d_geom, (int)sc->n,
+                       (long long)n, d_o, d_d, d_t, d_i);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(index, d_i, n * 4, hipMemcpyDeviceToHost));
+    g_err[0] = 0;
+    return RT_OK;
+}
+
+}  // extern "C"

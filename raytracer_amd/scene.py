@@ -1,0 +1,133 @@
+"""`Scene` — host-side mirror of the reference's renderer type (raytracer/Scene.fs:16-144).
+
+Same members as the F# class (`renderScene`, `saveFrameBuffer`, `saveDepthBuffer`) and the same
+state (`frameBuffer`, `depthBuffer`, `maxFrameBufferDepth`); the constants the reference
+hard-codes as `let` bindings (Scene.fs:18-43) are constructor arguments with the reference's
+values as defaults.  `renderScene` is one call through the C ABI (include/rt_abi.h) into
+librt_hip.so; there is no CPU rendering path here.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import abi, host
+
+
+class Scene:
+    def __init__(self, surfaces=None, width=800, height=640, samplesPerPixel=1, maxTraceDepth=5,
+                 backgroundColor=(0.0, 0.0, 0.0), cameraOriginWS=(-3.0, 6.0, 15.0), lookAt=(-1.0, 1.0, -10.0),
+                 fov=None, seed=1, jitter=1, lambertian_samples=0, device=0, slots_per_wave=0):
+        self.surfaces = list(host.SceneDefinitions.scene_spheres if surfaces is None else surfaces)   # Scene.fs:33
+        self.width, self.height = int(width), int(height)                                             # Scene.fs:18-19
+        self.samplesPerPixel, self.maxTraceDepth = int(samplesPerPixel), int(maxTraceDepth)           # Scene.fs:20,31
+        self.backgroundColor = tuple(backgroundColor)                                                 # Scene.fs:32
+        self.camera = host.make_camera(cameraOriginWS, lookAt, (0.0, 1.0, 0.0), fov)                  # Scene.fs:36-43
+        self.seed, self.jitter, self.lambertian_samples = int(seed), int(jitter), int(lambertian_samples)
+        self.device, self.slots_per_wave = int(device), int(slots_per_wave)
+        self.frameBuffer = np.zeros((self.width, self.height, 4), dtype=np.float32)                  # Scene.fs:28
+        self.depthBuffer = np.full((self.width, self.height), np.finfo(np.float32).max, dtype=np.float32)  # Scene.fs:29
+        self.objectIds = np.zeros((self.width, self.height), dtype=np.uint64)
+        self.maxFrameBufferDepth = 0.0                                                                # Scene.fs:30
+        self.rayCount = 0
+        self._lib = None
+        self._scene = C.c_void_p()
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def params(self, x_begin=0, x_end=None, x_step=1):
+        return host.make_params(self.width, self.height, self.samplesPerPixel, self.maxTraceDepth,
+                                self.backgroundColor, self.jitter, self.seed, self.lambertian_samples,
+                                x_begin, x_end, x_step, self.slots_per_wave)
+
+    def upload(self):
+        """Flatten the surfaces and upload them once to HBM (rt_scene_create)."""
+        if self._scene:
+            return self._scene
+        self._lib = abi.load_hip_library()
+        arr = host.flatten_surfaces(self.surfaces)
+        abi.check(self._lib, self._lib.rt_scene_create(arr, len(self.surfaces), self.device, C.byref(self._scene)))
+        return self._scene
+
+    def close(self):
+        if self._scene:
+            self._lib.rt_scene_destroy(self._scene)
+            self._scene = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- Scene.fs:117-121 -------------------------------------------------------------------
+    def renderScene(self):
+        self.upload()
+        p = self.params()
+        md, rays = C.c_float(0.0), C.c_uint64(0)
+        abi.check(self._lib, self._lib.rt_render(self._scene, C.byref(self.camera), C.byref(p),
+                                                 self.frameBuffer.ctypes.data, self.depthBuffer.ctypes.data,
+                                                 self.objectIds.ctypes.data, C.byref(md), C.byref(rays)))
+        self.maxFrameBufferDepth, self.rayCount = md.value, rays.value
+
+    def renderColumns(self, x_begin, x_end, x_step=1):
+        """Render the columns x_begin, x_begin+x_step, ... < x_end into compact host arrays
+        (the multi-GPU partition of include/rt_abi.h). Returns (rgba, depth, ids, max_depth, rays)."""
+        self.upload()
+        p = self.params(x_begin, x_end, x_step)
+        ncols = host.num_columns(p)
+        rgba = np.zeros((ncols, self.height, 4), dtype=np.float32)
+        depth = np.zeros((ncols, self.height), dtype=np.float32)
+        ids = np.zeros((ncols, self.height), dtype=np.uint64)
+        md, rays = C.c_float(0.0), C.c_uint64(0)
+        abi.check(self._lib, self._lib.rt_render(self._scene, C.byref(self.camera), C.byref(p), rgba.ctypes.data,
+                                                 depth.ctypes.data, ids.ctypes.data, C.byref(md), C.byref(rays)))
+        return rgba, depth, ids, md.value, rays.value
+
+    def renderColumnsDevice(self, d_rgba, d_depth, d_ids=None, d_stats=None, stream=None,
+                            x_begin=0, x_end=None, x_step=1):
+        """Asynchronous render into DEVICE buffers (raw pointers, e.g. torch `data_ptr()`), on `stream`
+        (a hipStream_t value, e.g. `torch.cuda.current_stream().cuda_stream`).  d_stats: 2 x u64."""
+        self.upload()
+        p = self.params(x_begin, x_end, x_step)
+        abi.check(self._lib, self._lib.rt_render_device(self._scene, C.byref(self.camera), C.byref(p),
+                                                        C.c_void_p(stream or 0), C.c_void_p(d_rgba), C.c_void_p(d_depth),
+                                                        C.c_void_p(d_ids or 0), C.c_void_p(d_stats or 0)))
+
+    def status(self):
+        self.upload()
+        abi.check(self._lib, self._lib.rt_scene_status(self._scene))
+
+    def findClosestIntersection(self, origins, directions):
+        """Batch form of Surface.fs:49-58 on the device: returns (t, index) arrays."""
+        self.upload()
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        t = np.empty(len(o), dtype=np.float32)
+        idx = np.empty(len(o), dtype=np.int32)
+        abi.check(self._lib, self._lib.rt_find_closest(self._scene, len(o), o.ctypes.data, d.ctypes.data,
+                                                       t.ctypes.data, idx.ctypes.data))
+        return t, idx
+
+    # -- Scene.fs:123-144 (PNG instead of JPEG: lossless, no ImageSharp) -------------------------
+    @staticmethod
+    def _to_rgba32(v):
+        """Rgba32(Vector4): clamp to [0,1], scale by 255, round half away from zero."""
+        return np.floor(np.clip(v, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+
+    def frameBufferImage(self):
+        return self._to_rgba32(self.frameBuffer).transpose(1, 0, 2)          # image.Item(px,py): x = column
+
+    def depthBufferImage(self):
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            g = self.depthBuffer / np.float32(self.maxFrameBufferDepth)       # Scene.fs:139
+        g = np.nan_to_num(g, nan=1.0, posinf=1.0)
+        rgba = np.stack([g, g, g, np.ones_like(g)], axis=-1)
+        return self._to_rgba32(rgba).transpose(1, 0, 2)
+
+    def saveFrameBuffer(self, path="sphere.png"):
+        from PIL import Image
+        Image.fromarray(self.frameBufferImage(), "RGBA").convert("RGB").save(path)
+
+    def saveDepthBuffer(self, path="depth.png"):
+        from PIL import Image
+        Image.fromarray(self.depthBufferImage(), "RGBA").convert("RGB").save(path)

@@ -44,6 +44,10 @@ def load():
     lib.rto_generate_samples.argtypes = [P(abi.rt_surface), P(C.c_float), P(C.c_float), C.c_float,
                                          C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_float)]
     lib.rto_generate_samples.restype = C.c_int
+    lib.rto_find_closest.argtypes = [P(abi.rt_surface), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rto_find_closest.restype = None
+    lib.rto_set_raymap.argtypes = [C.c_void_p]
+    lib.rto_set_raymap.restype = None
     lib.rto_hemisphere_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_float)]
     lib.rto_unit_sphere_sample.argtypes = [C.c_uint64, C.c_uint64, P(C.c_float)]
     lib.rto_frame_around.argtypes = [P(C.c_float), P(C.c_float), P(C.c_float)]
@@ -74,3 +78,33 @@ def render(surfaces, cam, params, flags=0, nthreads=0):
     if r != 0:
         raise RuntimeError(f"rto_render failed: {r}")
     return dict(rgba=rgba, depth=depth, ids=ids, max_depth=md.value, rays=rc.value)
+
+
+def find_closest(surfaces, origins, directions):
+    """Oracle findClosestIntersection for a batch of rays. Returns (t, index)."""
+    lib = load()
+    arr = host.flatten_surfaces(surfaces) if isinstance(surfaces, (list, tuple)) else surfaces
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    t = np.empty(len(o), dtype=np.float32)
+    idx = np.empty(len(o), dtype=np.int32)
+    lib.rto_find_closest(arr, len(surfaces), len(o), o.ctypes.data, d.ctypes.data, t.ctypes.data, idx.ctypes.data)
+    return t, idx
+
+
+def intersect(surface, o, d, dot_view=1.0):
+    """Hitable.Intersect + IntersectionAcceptable for one surface. Returns (has, t, acceptable)."""
+    lib = load()
+    s = surface.flatten() if isinstance(surface, host.Surface) else surface
+    has, acc, t = C.c_int(0), C.c_int(0), C.c_float(0)
+    lib.rto_intersect(C.byref(s), f3(o), f3(d), dot_view, C.byref(has), C.byref(t), C.byref(acc))
+    return bool(has.value), t.value, bool(acc.value)
+
+
+def generate_samples(surface, o, d, t, seed=1, ps=0, node=0):
+    """Surface.GenerateSamples. Returns (n, dirs[n,3], shading[n,3])."""
+    lib = load()
+    s = surface.flatten() if isinstance(surface, host.Surface) else surface
+    dirs, sh = (C.c_float * 12)(), (C.c_float * 12)()
+    n = lib.rto_generate_samples(C.byref(s), f3(o), f3(d), t, seed, ps, node, dirs, sh)
+    return n, np.array(dirs[:3 * n], dtype=np.float32).reshape(n, 3), np.array(sh[:3 * n], dtype=np.float32).reshape(n, 3)
