@@ -104,10 +104,12 @@ def main():
         bufs = dict(
             rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
             depth=torch.zeros((ncols, sc.height), dtype=torch.float32, device=dev),
-            stats=torch.zeros(2, dtype=torch.int64, device=dev),
+            stats=torch.zeros(4, dtype=torch.int64, device=dev),
         )
         g = multi.FrameGatherer(sc.width, sc.height, dev, rank, world)
         return sc, (xb, xe, xs), bufs, g
+
+    diag = {}
 
     def step(sc, cols, bufs, g, ev=None):
         stream = torch.cuda.current_stream().cuda_stream
@@ -119,6 +121,7 @@ def main():
             ev[1].record()
         st = bufs["stats"].cpu()        # syncs this stream: ray count + max depth bits of this rank
         rays = int(st[0].item())
+        diag["iters"], diag["prim_iters"] = int(st[2].item()), int(st[3].item())
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
         return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
 
@@ -160,7 +163,9 @@ def main():
                        "rays_per_frame": rays_per_frame, "partition": "interleaved columns, %d rank(s), RCCL gather to rank 0" % world},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "rt::render_kernel", "kernel_ms": kern_ms, "flops_per_ray": FLOPS_PER_RAY},
+                         "kernel": "rt::render_kernel", "kernel_ms": kern_ms, "flops_per_ray": FLOPS_PER_RAY,
+                         "lane_fill": local_rays / max(1, diag.get("iters", 0) * 64), "iters": diag.get("iters"),
+                         "prim_iters": diag.get("prim_iters")},
         }
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}

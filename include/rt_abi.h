@@ -118,8 +118,11 @@ int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
 
 /* Same render, but asynchronous on `stream` (a hipStream_t; NULL = default stream) with DEVICE
  * output buffers, so a caller that owns device memory (torch, RCCL gather of the framebuffer)
- * never crosses PCIe.  d_stats points at 2 device u64: [0] ray count, [1] bit pattern of
- * max depth (f32) in the low word; may be NULL.  No counterpart in the reference.             */
+ * never crosses PCIe.  d_stats points at RT_STATS_WORDS device u64: [0] ray count, [1] bit pattern
+ * of max depth (f32) in the low word, [2] 64-ray loop iterations over all waves, [3] iterations
+ * that started primary rays (the last two are diagnostics); may be NULL.
+ * No counterpart in the reference.                                                            */
+#define RT_STATS_WORDS 4
 int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);

@@ -1,0 +1,7 @@
+import json,sys
+for f in sys.argv[1:]:
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); r=d["roofline"]
+        print(f.split('/')[-1], "Mrays/s=%.0f ms=%.2f kern_ms=%.2f fill=%.3f iters=%s prim_iters=%s" % (d["value"], d["ms_per_step"], r["kernel_ms"], r["lane_fill"], r["iters"], r["prim_iters"]))
+    except Exception as e:
+        print(f, "ERR", e, open(f).read()[-300:])

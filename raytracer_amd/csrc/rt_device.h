@@ -64,9 +64,38 @@ RT_DEV f3 neg(f3 a) { return F3(-a.x, -a.y, -a.z); }
 // Vector3.Dot: (x*x' + y*y') + z*z'
 RT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+// ---- correctly rounded f32 sqrt and divide, normal-range operands --------------------------------
+// hipcc's IEEE lowerings of sqrtf and '/' are v_sqrt_f32 / v_rcp_f32 plus an FMA correction that makes
+// the result correctly rounded, wrapped in scaling code for subnormal operands and results (x < 2^-96,
+// quotients near the subnormal range).  Every operand on the ray path is a normal number (lengths of
+// unit-scale vectors, discriminants >= 5e-4, |denominators| >= 1e-3 whenever the quotient is used), so
+// the same correction is applied here without the scaling: 9 instead of 15 instructions per sqrt, 8
+// instead of 11 per divide, bit-identical results on that range (tests compare t bit for bit).
+RT_DEV float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);                       // within 1 ulp
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x);
+    const float r_up = __builtin_fmaf(-s_up, s, x);
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
+RT_DEV float div_rn(float n, float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);                               // within 1 ulp
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return q;
+}
+
 // Vector3 / float : one reciprocal, three multiplies
-RT_DEV f3 divs(f3 a, float s) { float inv = 1.0f / s; return F3(a.x * inv, a.y * inv, a.z * inv); }
-RT_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+RT_DEV f3 divs(f3 a, float s) { float inv = div_rn(1.0f, s); return F3(a.x * inv, a.y * inv, a.z * inv); }
+RT_DEV float length(f3 a) { return sqrt_rn(dot(a, a)); }
 RT_DEV f3 normalize(f3 a) { return divs(a, length(a)); }
 
 // Numerics.fs:9  MathF.Round(x, digits) with p = 10^digits, midpoint to even
@@ -75,19 +104,26 @@ RT_DEV float round_digits(float x, float p)
     if (fabsf(x) < 1e8f) { x = x * p; x = rintf(x); x = x / p; }
     return x;
 }
-// Numerics.fs:12-16 via the Ray constructor, Geometry/Core.fs:21
-RT_DEV f3 normalized_or_fail(f3 v)
-{
-    float len = length(v);
-    if (round_digits(len, 1e5f) == 1.0f) return v;
-    return divs(v, len);
-}
+// Round(x, digits) == k / p for an integer k (as a float): since p = 10^digits is exact and k/p is
+// correctly rounded, the quotient equals target/p only when rint(x*p) == target (neighbouring
+// integers differ by 1/p >> ulp).  Saves the division of round_digits; |x| < 1e8 as in MathF.Round.
+RT_DEV bool rounds_to(float x, float p, float target) { return fabsf(x) < 1e8f && rintf(x * p) == target; }
+
+// The Ray constructor (Geometry/Core.fs:21) renormalises its direction only when
+// Round(|d|,5) <> 1 (NormalizedOrFail, Numerics.fs:12-16).  Every direction built here is the
+// output of Vector3.Normalize, whose f32 length is within 1e-6 of 1 (three roundings of
+// ~6e-8 each), far inside the 5e-6 window of Round(.,5) = 1: the test can never fire, so the
+// direction is returned as is.  (tests/test_gpu_parity.py covers this through bit-exact t.)
+RT_DEV f3 make_ray_dir(f3 normalized) { return normalized; }
 
 // ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter =
 //      (pixel-sample index, ray-tree node index); replaces Henzai.Core RandomSampling.
 RT_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                           uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
 {
+    // opaque copy of the key: keeps the ten-round key schedule (18 scalar adds) next to its use instead of
+    // in 18 (or, once SLP-paired, 36) loop-invariant SGPRs that spill in the closest-hit loop
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -129,7 +165,7 @@ RT_DEV f3 hemisphere_sample(uint32_t seed_lo, uint32_t seed_hi, uint64_t ps, uin
     philox4x32_10((uint32_t)ps, (uint32_t)(ps >> 32), (uint32_t)node, (uint32_t)(node >> 32), seed_lo, seed_hi,
                   w0, w1, w2, w3);
     float r1 = u01(w0), r2 = u01(w1);
-    float sin_theta = sqrtf(1.0f - r1 * r1);
+    float sin_theta = sqrt_rn(1.0f - r1 * r1);
     float s, c;
     sincos_2pi(r2, s, c);
     return F3(sin_theta * c, r1, sin_theta * s);
@@ -152,7 +188,7 @@ RT_DEV void frame_around(f3 n, f3& nt, f3& nb)
     bool xbig = fabsf(n.x) > fabsf(n.y);
     f3 a = xbig ? F3(n.z, 0.0f, -n.x) : F3(0.0f, -n.z, n.y);
     float l2 = xbig ? (n.x * n.x + n.z * n.z) : (n.y * n.y + n.z * n.z);
-    nt = divs(a, sqrtf(l2));
+    nt = divs(a, sqrt_rn(l2));
     nb = cross(n, nt);
 }
 
@@ -165,40 +201,53 @@ RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D,
 {
     int idx = -1;
     float tmin = kFltMax;
+    // The record of surface i+1 is requested (five s_load_dwordx4) before surface i is evaluated, so
+    // the scalar-cache latency overlaps the arithmetic; conditions are combined with '&' so that no
+    // short-circuit branch (and no load behind it) is generated.
+    const float4* __restrict__ gp = reinterpret_cast<const float4*>(geom);
+    float4 ra, rb, rc, rd, re;
+    if (nsurf > 0) { ra = gp[0]; rb = gp[1]; rc = gp[2]; rd = gp[3]; re = gp[4]; }
     for (int i = 0; i < nsurf; i++) {
-        const GeomRec* g = geom + i;
-        const int type = g->type;
+        const int j = (i + 1 < nsurf) ? i + 1 : i;
+        const float4 na = gp[5 * j + 0], nb = gp[5 * j + 1], nc = gp[5 * j + 2], nd = gp[5 * j + 3], ne = gp[5 * j + 4];
+        const int type = __float_as_int(re.y);
         float t; bool ok;
         if (type == kGeomSphere) {
             // Sphere.fs:18-36,42-43
-            f3 ctr = O - F3(g->a[0], g->a[1], g->a[2]);
-            float B = 2.0f * dot(ctr, D);
-            float C = dot(ctr, ctr) - g->a[3];
-            float disc = B * B - 4.0f * C;
-            bool has = !(disc < 0.0f) && !(round_digits(disc, 1e3f) == 0.0f);
-            float sq = sqrtf(disc);
-            float i1 = (-B + sq) / 2.0f, i2 = (-B - sq) / 2.0f;
-            t = (i1 >= kTMin && i2 >= kTMin) ? ((i1 < i2) ? i1 : i2) : ((i1 < 0.0f) ? i2 : i1);
-            ok = has && t > kTMin;
+            const f3 ctr = O - F3(ra.x, ra.y, ra.z);
+            const float B = 2.0f * dot(ctr, D);
+            const float C = dot(ctr, ctr) - ra.w;
+            const float disc = B * B - 4.0f * C;
+            const bool has = !(disc < 0.0f) & !rounds_to(disc, 1e3f, 0.0f);
+            const float sq = sqrt_rn(disc);
+            const float i1 = (-B + sq) / 2.0f, i2 = (-B - sq) / 2.0f;
+            const float tboth = (i1 < i2) ? i1 : i2;
+            const float tone = (i1 < 0.0f) ? i2 : i1;
+            t = ((i1 >= kTMin) & (i2 >= kTMin)) ? tboth : tone;
+            ok = has & (t > kTMin);
         } else {
             // Plane.fs:36-40,45-49
-            f3 N = F3(g->a[0], g->a[1], g->a[2]);
-            float num = -g->a[3] - dot(N, O);
-            float den = dot(N, D);
-            bool has = !(fabsf(den) < kTMin);
-            t = num / den;
-            ok = has && t > kTMin && t <= (kTMax / 1.0f);
+            const f3 N = F3(ra.x, ra.y, ra.z);
+            const float num = -ra.w - dot(N, O);
+            const float den = dot(N, D);
+            const bool has = !(fabsf(den) < kTMin);
+            t = div_rn(num, den);
+            ok = has & (t > kTMin) & (t <= (kTMax / 1.0f));
             if (type == kGeomPlaneRect) {
                 // Plane.fs:19-34 with the per-plane constants hoisted
-                f3 P = O + D * t;                                    // Core.fs:59
-                f3 kern = F3(g->d[0], g->d[1], g->d[2]);
-                f3 v = P - kern;
-                float nx = kern.x + (((v.x * g->b[0] + v.y * g->b[1]) + v.z * g->b[2]) + 0.0f);
-                float ny = kern.y + (((v.x * g->c[0] + v.y * g->c[1]) + v.z * g->c[2]) + 0.0f);
-                ok = ok && nx <= g->b[3] && nx >= g->c[3] && ny <= g->d[3] && ny >= g->ymin;
+                const f3 P = O + D * t;                                    // Core.fs:59
+                const f3 kern = F3(rd.x, rd.y, rd.z);
+                const f3 v = P - kern;
+                const float nx = kern.x + (((v.x * rb.x + v.y * rb.y) + v.z * rb.z) + 0.0f);
+                const float ny = kern.y + (((v.x * rc.x + v.y * rc.y) + v.z * rc.z) + 0.0f);
+                // xmin <= nx <= xmax  <=>  med3(nx, xmin, xmax) == nx  (bounds ordered: w, h >= 0)
+                ok = ok & (__builtin_amdgcn_fmed3f(nx, rc.w, rb.w) == nx) & (__builtin_amdgcn_fmed3f(ny, re.x, rd.w) == ny);
             }
         }
-        if (ok && t < tmin) { tmin = t; idx = i; }
+        const bool better = ok & (t < tmin);
+        tmin = better ? t : tmin;
+        idx = better ? i : idx;
+        ra = na; rb = nb; rc = nc; rd = nd; re = ne;
     }
     idx_out = idx; t_out = tmin;
 }

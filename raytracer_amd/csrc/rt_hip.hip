@@ -141,17 +141,17 @@ int check_params(const rt_camera* cam, const rt_params* p)
 }
 
 template <int S>
-int launch_render(const RenderArgs& a, const GeomRec* geom, const ShadeRec* shade, bool node64, dim3 grid,
+int launch_render(const ColdArgs& c, const RenderArgs& a, const GeomRec* geom, const ShadeRec* shade, bool node64, dim3 grid,
                   size_t smem, hipStream_t stream)
 {
     if (node64) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<S, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((render_kernel<S, true>), grid, dim3(64), smem, stream, a, geom, shade);
+        hipLaunchKernelGGL((render_kernel<S, true>), grid, dim3(64), smem, stream, c, a, geom, shade);
     } else {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<S, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((render_kernel<S, false>), grid, dim3(64), smem, stream, a, geom, shade);
+        hipLaunchKernelGGL((render_kernel<S, false>), grid, dim3(64), smem, stream, c, a, geom, shade);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -203,6 +203,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             g.a[0] = nraw.x; g.a[1] = nraw.y; g.a[2] = nraw.z; g.a[3] = d;
             h.nc[0] = pn.x; h.nc[1] = pn.y; h.nc[2] = pn.z;
             if (s.g[4] != 0.0f) {
+                if (!(s.g[8] >= 0.0f) || !(s.g[9] >= 0.0f)) { delete sc; return fail(RT_E_INVALID, "surface %lld: negative rectangle size", (long long)i); }
                 gtype = kGeomPlaneRect;
                 // Plane.fs:19-30: R, kern and the rotated centre are per-plane constants
                 const M4 R = rotation_between_unit_vectors(pn, H3{ 0.0f, 0.0f, -1.0f });
@@ -270,60 +271,67 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
 
     const int ncols = (p->x_end - p->x_begin + p->x_step - 1) / p->x_step;
     if (ncols <= 0) return RT_OK;
-    const int S = p->slots_per_wave ? p->slots_per_wave : 64;
+    if (sc->n > kMaxPoolSurfaces)
+        return fail(RT_E_UNSUPPORTED, "the linear-scan kernel handles at most %d surfaces (got %lld)", kMaxPoolSurfaces, (long long)sc->n);
+    // slots per wave: larger batches amortise the end-of-batch tail, smaller ones give small frames
+    // enough waves to fill 256 CUs x 8 waves
+    const long long nps = (long long)ncols * p->height * p->spp;
+    const int S = p->slots_per_wave ? p->slots_per_wave : (nps >= 256LL * 8192 ? 256 : (nps >= 128LL * 8192 ? 128 : 64));
     const int lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
     const ShadeRec* shade = nullptr;
     rc = shade_table(sc, lamb, &shade);
     if (rc) return rc;
 
     RenderArgs a; memset(&a, 0, sizeof a);
-    a.rgba = d_rgba; a.depth = d_depth;
-    a.ids = reinterpret_cast<unsigned long long*>(d_object_id);
-    a.stats = reinterpret_cast<unsigned long long*>(d_stats);
-    a.status = sc->d_status;
-    a.nsurf = (int)sc->n; a.W = p->width; a.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
-    a.jitter = p->jitter ? 1 : 0;
+    ColdArgs c; memset(&c, 0, sizeof c);
+    c.rgba = d_rgba; c.depth = d_depth;
+    c.ids = reinterpret_cast<unsigned long long*>(d_object_id);
+    c.stats = reinterpret_cast<unsigned long long*>(d_stats);
+    c.status = sc->d_status;
+    a.nsurf = (int)sc->n; c.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
+    c.jitter = p->jitter ? 1 : 0;
     a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
-    a.x_begin = p->x_begin; a.x_step = p->x_step; a.ncols = ncols;
+    c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
-    for (int c = 0; c < 3; c++) a.bg[c] = p->background[c];
+    for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
 
-    // pool bound: S level-0 records + 64 per deeper record level (DESIGN.md "Pool bound")
-    a.cap = S + 64 * (p->max_trace_depth + a.bg_nonzero);
+    // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
+    // (DESIGN.md "Pool bound")
+    a.cap = 64 * (p->max_trace_depth + 1 + a.bg_nonzero);
     // pixel tile per wave
     int G = 1;
     if (p->spp < S) { while (G * 2 * p->spp <= S) G *= 2; }
     int gl = 0; while ((1 << gl) < G) gl++;
-    a.tw_log2 = gl / 2; a.th_log2 = gl - gl / 2;
+    c.tw_log2 = gl / 2; c.th_log2 = gl - gl / 2;
     a.pix_per_group = G;
     a.passes = (p->spp > S) ? (p->spp + S - 1) / S : 1;
-    const int tw = 1 << a.tw_log2, th = 1 << a.th_log2;
-    a.ntx = (ncols + tw - 1) / tw;
+    const int tw = 1 << c.tw_log2, th = 1 << c.th_log2;
+    c.ntx = (ncols + tw - 1) / tw;
     const long long nty = (p->height + th - 1) / th;
-    const long long ngroups = (long long)a.ntx * nty;
+    const long long ngroups = (long long)c.ntx * nty;
     if (ngroups > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
 
     // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
     const float* M = cam->cam_to_world;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.rot[3 * i + j] = M[4 * i + j];
-    a.origin[0] = M[12]; a.origin[1] = M[13]; a.origin[2] = M[14];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.rot[3 * i + j] = M[4 * i + j];
+    c.origin[0] = M[12]; c.origin[1] = M[13]; c.origin[2] = M[14];
     const H3 ln = hnormalize(H3{ cam->look_at[0], cam->look_at[1], cam->look_at[2] });
-    a.look_n[0] = ln.x; a.look_n[1] = ln.y; a.look_n[2] = ln.z;
-    a.fw = (float)p->width; a.fh = (float)p->height;
-    a.aspect = a.fw / a.fh;
-    a.tan_half = tanf(cam->fov / 2.0f);
+    c.look_n[0] = ln.x; c.look_n[1] = ln.y; c.look_n[2] = ln.z;
+    c.fw = (float)p->width; c.fh = (float)p->height;
+    c.aspect = c.fw / c.fh;
+    c.tan_half = tanf(cam->fov / 2.0f);
 
     const bool node64 = p->max_trace_depth > 13;
-    const size_t smem = sizeof(uint32_t) * ((size_t)S * 5 + 64 + (size_t)(node64 ? 13 : 12) * a.cap);
+    const size_t smem = sizeof(uint32_t) * ((size_t)S * 5 + 64 + (size_t)(node64 ? 12 : 11) * a.cap);
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
-    if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, 2 * sizeof(uint64_t), stream));
+    if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
     const dim3 grid((unsigned)ngroups);
     switch (S) {
-    case 64:  return launch_render<64>(a, sc->d_geom, shade, node64, grid, smem, stream);
-    case 128: return launch_render<128>(a, sc->d_geom, shade, node64, grid, smem, stream);
-    default:  return launch_render<256>(a, sc->d_geom, shade, node64, grid, smem, stream);
+    case 64:  return launch_render<64>(c, a, sc->d_geom, shade, node64, grid, smem, stream);
+    case 128: return launch_render<128>(c, a, sc->d_geom, shade, node64, grid, smem, stream);
+    default:  return launch_render<256>(c, a, sc->d_geom, shade, node64, grid, smem, stream);
     }
 }
 
@@ -348,8 +356,8 @@ int rt_render(rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgb
     const size_t ncols = (size_t)((p->x_end - p->x_begin + p->x_step - 1) / p->x_step);
     const size_t npix = ncols * (size_t)p->height;
     if (npix == 0) { if (max_depth) *max_depth = 0.0f; if (ray_count) *ray_count = 0; return RT_OK; }
-    // staging layout: stats (16 B) | ids (8 B each) | rgba (16 B each) | depth (4 B each)
-    const size_t off_ids = 16, off_rgba = off_ids + npix * 8, off_depth = off_rgba + npix * 16;
+    // staging layout: stats | ids (8 B each) | rgba (16 B each) | depth (4 B each)
+    const size_t off_ids = RT_STATS_WORDS * 8, off_rgba = off_ids + npix * 8, off_depth = off_rgba + npix * 16;
     rc = ensure_tmp(sc, off_depth + npix * 4);
     if (rc) return rc;
     char* base = reinterpret_cast<char*>(sc->d_tmp);
