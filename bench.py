@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4s", choices=sorted(WORKLOADS))
-    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -99,12 +99,12 @@ def main():
 
     def make(wl):
         cfg = WORKLOADS[wl]
-        sc = Scene(device=local_rank, slots_per_wave=args.slots, **cfg)
+        sc = Scene(device=local_rank, waves_per_cu=args.waves_per_cu, **cfg)
         xb, xe, xs, ncols = multi.columns_of_rank(sc.width, rank, world)
         bufs = dict(
             rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
             depth=torch.zeros((ncols, sc.height), dtype=torch.float32, device=dev),
-            stats=torch.zeros(4, dtype=torch.int64, device=dev),
+            stats=torch.zeros(8, dtype=torch.int64, device=dev),
         )
         g = multi.FrameGatherer(sc.width, sc.height, dev, rank, world)
         return sc, (xb, xe, xs), bufs, g
@@ -122,6 +122,7 @@ def main():
         st = bufs["stats"].cpu()        # syncs this stream: ray count + max depth bits of this rank
         rays = int(st[0].item())
         diag["iters"], diag["prim_iters"] = int(st[2].item()), int(st[3].item())
+        diag["max_wave_iters"], diag["max_wave_clk"], diag["sum_wave_clk"], diag["waves"] = (int(st[i].item()) for i in (4, 5, 6, 7))
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
         return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
 
@@ -165,7 +166,9 @@ def main():
                          "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
                          "kernel": "rt::render_kernel", "kernel_ms": kern_ms, "flops_per_ray": FLOPS_PER_RAY,
                          "lane_fill": local_rays / max(1, diag.get("iters", 0) * 64), "iters": diag.get("iters"),
-                         "prim_iters": diag.get("prim_iters")},
+                         "prim_iters": diag.get("prim_iters"), "waves": diag.get("waves"),
+                         "max_wave_iters": diag.get("max_wave_iters"), "max_wave_clk": diag.get("max_wave_clk"),
+                         "mean_wave_clk": diag.get("sum_wave_clk", 0) / max(1, diag.get("waves", 1))},
         }
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}

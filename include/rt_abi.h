@@ -36,7 +36,7 @@ extern "C" {
 #define RT_E_INVALID      -1   /* bad argument (null pointer, size, enum value)              */
 #define RT_E_NO_DEVICE    -2   /* no HIP device / device index out of range                  */
 #define RT_E_HIP          -3   /* a HIP runtime call failed (message has the HIP error)      */
-#define RT_E_OVERFLOW     -4   /* the in-LDS ray pool overflowed its proven bound (a bug)    */
+#define RT_E_OVERFLOW     -4   /* a wave's LDS record pool overflowed its proven bound (a bug) */
 #define RT_E_UNSUPPORTED  -5   /* valid request this build does not implement                */
 
 /* ---- surface kinds: the Surface subclasses of raytracer/Surface.fs ---------------------- */
@@ -96,7 +96,7 @@ typedef struct rt_params {
     uint64_t seed;                /* Philox4x32-10 key                                        */
     int32_t  lambertian_samples;  /* Lambertian SampleCount; 0 = 4 (Surface.fs:63); 1..4      */
     int32_t  x_begin, x_end, x_step;
-    int32_t  slots_per_wave;      /* tuning: pixel-samples one wave traces together; 0 = auto */
+    int32_t  waves_per_cu;        /* tuning: cap on resident persistent waves per CU; 0 = all that fit */
 } rt_params;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident SoA scene + workspace          */
@@ -120,9 +120,10 @@ int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
  * output buffers, so a caller that owns device memory (torch, RCCL gather of the framebuffer)
  * never crosses PCIe.  d_stats points at RT_STATS_WORDS device u64: [0] ray count, [1] bit pattern
  * of max depth (f32) in the low word, [2] 64-ray loop iterations over all waves, [3] iterations
- * that started primary rays (the last two are diagnostics); may be NULL.
+ * that started primary rays, [4] most iterations of one wave, [5] longest / [6] summed wave lifetime
+ * in shader clocks, [7] waves ([2..7] are diagnostics); may be NULL.
  * No counterpart in the reference.                                                            */
-#define RT_STATS_WORDS 4
+#define RT_STATS_WORDS 8
 int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);
@@ -144,7 +145,7 @@ const char* rt_last_error(void);
 
 /* ABI version: bumped whenever a struct layout or signature changes.                         */
 int  rt_abi_version(void);
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 #ifdef __cplusplus
 }

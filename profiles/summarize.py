@@ -19,7 +19,7 @@ for pdb in sorted(glob.glob(os.path.join(src, "pmc*", "*.db"))):
     c = sqlite3.connect(pdb)
     acc = defaultdict(lambda: defaultdict(float)); nd = defaultdict(set)
     for kname, disp, cname, val in c.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
-        if "render_kernel" not in kname and "bvh" not in kname:
+        if "render_kernel" not in kname and "trace_kernel" not in kname:
             continue
         k = kname.split("(")[0]
         acc[k][cname] += val; nd[k].add(disp)

@@ -19,7 +19,7 @@ RT_E_UNSUPPORTED = -5
 KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 
 
 class rt_surface(C.Structure):
@@ -57,7 +57,7 @@ class rt_params(C.Structure):
         ("x_begin", C.c_int32),
         ("x_end", C.c_int32),
         ("x_step", C.c_int32),
-        ("slots_per_wave", C.c_int32),
+        ("waves_per_cu", C.c_int32),
     ]
 
 

@@ -96,6 +96,12 @@ struct rt_scene {
     GeomRec* d_geom = nullptr;
     ShadeRec* d_shade[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // index = Lambertian SampleCount default (1..4)
     int* d_status = nullptr;
+    unsigned long long* d_counter = nullptr;   // work counter of the persistent waves
+    unsigned long long* d_accum = nullptr;     // per-pixel 32.32 radiance sums (grown on demand)
+    size_t accum_bytes = 0;
+    int num_cus = 0;
+    int occ_smem[2] = { -1, -1 };              // LDS size the cached occupancy below was queried for
+    int occ_per_cu[2] = { 0, 0 };
     float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
     size_t tmp_bytes = 0;
     std::vector<ShadeRec> h_shade;      // with nsamples of Lambertian-default surfaces left 0
@@ -135,24 +141,41 @@ int check_params(const rt_camera* cam, const rt_params* p)
     if (p->lambertian_samples < 0 || p->lambertian_samples > 4) return fail(RT_E_INVALID, "lambertian_samples must be in 0..4");
     if (p->x_step <= 0 || p->x_begin < 0 || p->x_end > p->width || p->x_begin > p->x_end)
         return fail(RT_E_INVALID, "bad column range x_begin/x_end/x_step");
-    if (p->slots_per_wave != 0 && p->slots_per_wave != 64 && p->slots_per_wave != 128 && p->slots_per_wave != 256)
-        return fail(RT_E_INVALID, "slots_per_wave must be 0, 64, 128 or 256");
+    if (p->waves_per_cu < 0 || p->waves_per_cu > 32) return fail(RT_E_INVALID, "waves_per_cu must be in 0..32");
     return RT_OK;
 }
 
-template <int S>
-int launch_render(const ColdArgs& c, const RenderArgs& a, const GeomRec* geom, const ShadeRec* shade, bool node64, dim3 grid,
-                  size_t smem, hipStream_t stream)
+int ensure_accum(rt_scene* sc, size_t bytes)
 {
-    if (node64) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<S, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((render_kernel<S, true>), grid, dim3(64), smem, stream, c, a, geom, shade);
-    } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel<S, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((render_kernel<S, false>), grid, dim3(64), smem, stream, c, a, geom, shade);
+    if (sc->accum_bytes >= bytes) return RT_OK;
+    if (sc->d_accum) { HIP_TRY(hipFree(sc->d_accum)); sc->d_accum = nullptr; sc->accum_bytes = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_accum), bytes));
+    sc->accum_bytes = bytes;
+    return RT_OK;
+}
+
+template <bool NODE64>
+int launch_trace(rt_scene* sc, const ColdArgs& c, const RenderArgs& a, const ShadeRec* shade, int waves_per_cu,
+                 size_t smem, hipStream_t stream)
+{
+    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64>);
+    // the attribute and the occupancy query cost host time: once per (kernel, LDS size) and scene
+    int& cached_smem = sc->occ_smem[NODE64 ? 1 : 0];
+    int& cached_per_cu = sc->occ_per_cu[NODE64 ? 1 : 0];
+    if (cached_smem != (int)smem) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int q = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 64, smem));
+        cached_per_cu = q < 1 ? 1 : q;
+        cached_smem = (int)smem;
     }
+    int per_cu = cached_per_cu;
+    if (waves_per_cu > 0 && waves_per_cu < per_cu) per_cu = waves_per_cu;
+    // persistent waves: no more than fit on the chip, no more than there are 64-sample refills
+    const unsigned long long chunks = (c.total + 63) / 64;
+    unsigned long long grid = (unsigned long long)per_cu * (unsigned long long)sc->num_cus;
+    if (grid > chunks) grid = chunks;
+    hipLaunchKernelGGL((trace_kernel<NODE64>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, shade);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -239,6 +262,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (e == hipSuccess && n > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * (size_t)n, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_status), sizeof(int));
     if (e == hipSuccess) e = hipMemset(sc->d_status, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_counter), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&sc->num_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) {
         rt_scene_destroy(sc);
         return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
@@ -255,6 +280,8 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_geom) (void)hipFree(sc->d_geom);
     for (ShadeRec* p : sc->d_shade) if (p) (void)hipFree(p);
     if (sc->d_status) (void)hipFree(sc->d_status);
+    if (sc->d_counter) (void)hipFree(sc->d_counter);
+    if (sc->d_accum) (void)hipFree(sc->d_accum);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
     delete sc;
 }
@@ -273,43 +300,39 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     if (ncols <= 0) return RT_OK;
     if (sc->n > kMaxPoolSurfaces)
         return fail(RT_E_UNSUPPORTED, "the linear-scan kernel handles at most %d surfaces (got %lld)", kMaxPoolSurfaces, (long long)sc->n);
-    // slots per wave: larger batches amortise the end-of-batch tail, smaller ones give small frames
-    // enough waves to fill 256 CUs x 8 waves
-    const long long nps = (long long)ncols * p->height * p->spp;
-    const int S = p->slots_per_wave ? p->slots_per_wave : (nps >= 256LL * 8192 ? 256 : (nps >= 128LL * 8192 ? 128 : 64));
+    const long long npix = (long long)ncols * p->height;
+    if (npix > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
     const int lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
     const ShadeRec* shade = nullptr;
     rc = shade_table(sc, lamb, &shade);
     if (rc) return rc;
+    rc = ensure_accum(sc, (size_t)npix * 3 * sizeof(unsigned long long));
+    if (rc) return rc;
 
     RenderArgs a; memset(&a, 0, sizeof a);
     ColdArgs c; memset(&c, 0, sizeof c);
-    c.rgba = d_rgba; c.depth = d_depth;
+    c.accum = sc->d_accum; c.counter = sc->d_counter; c.depth = d_depth;
     c.ids = reinterpret_cast<unsigned long long*>(d_object_id);
     c.stats = reinterpret_cast<unsigned long long*>(d_stats);
     c.status = sc->d_status;
+    c.total = (unsigned long long)npix * (unsigned long long)p->spp;
+    c.npix = (unsigned int)npix;
+    {   // multiplier of the hand-out permutation: near npix/phi, coprime with npix
+        unsigned long long m = (unsigned long long)((double)npix * 0.6180339887498949) | 1ull;
+        auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long t = x % y; x = y; y = t; } return x; };
+        while (gcd(m, (unsigned long long)npix) != 1) m += 2;
+        c.scatter = (unsigned int)(m % (unsigned long long)npix);
+        if (npix == 1) c.scatter = 0;
+    }
     a.nsurf = (int)sc->n; c.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
     c.jitter = p->jitter ? 1 : 0;
     a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
     c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
-
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
     // (DESIGN.md "Pool bound")
     a.cap = 64 * (p->max_trace_depth + 1 + a.bg_nonzero);
-    // pixel tile per wave
-    int G = 1;
-    if (p->spp < S) { while (G * 2 * p->spp <= S) G *= 2; }
-    int gl = 0; while ((1 << gl) < G) gl++;
-    c.tw_log2 = gl / 2; c.th_log2 = gl - gl / 2;
-    a.pix_per_group = G;
-    a.passes = (p->spp > S) ? (p->spp + S - 1) / S : 1;
-    const int tw = 1 << c.tw_log2, th = 1 << c.th_log2;
-    c.ntx = (ncols + tw - 1) / tw;
-    const long long nty = (p->height + th - 1) / th;
-    const long long ngroups = (long long)c.ntx * nty;
-    if (ngroups > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
 
     // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
     const float* M = cam->cam_to_world;
@@ -322,17 +345,20 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     c.tan_half = tanf(cam->fov / 2.0f);
 
     const bool node64 = p->max_trace_depth > 13;
-    const size_t smem = sizeof(uint32_t) * ((size_t)S * 5 + 64 + (size_t)(node64 ? 12 : 11) * a.cap);
+    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)(node64 ? 12 : 11) * a.cap);
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_accum, 0, (size_t)npix * 3 * sizeof(unsigned long long), stream));
     if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
-    const dim3 grid((unsigned)ngroups);
-    switch (S) {
-    case 64:  return launch_render<64>(c, a, sc->d_geom, shade, node64, grid, smem, stream);
-    case 128: return launch_render<128>(c, a, sc->d_geom, shade, node64, grid, smem, stream);
-    default:  return launch_render<256>(c, a, sc->d_geom, shade, node64, grid, smem, stream);
-    }
+    rc = node64 ? launch_trace<true>(sc, c, a, shade, p->waves_per_cu, smem, stream)
+                : launch_trace<false>(sc, c, a, shade, p->waves_per_cu, smem, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, sc->d_accum, d_rgba,
+                       npix, p->spp);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
 }
 
 int rt_scene_status(rt_scene* sc)

@@ -1,28 +1,36 @@
-// rt_kernels.h — the render kernel: one wave64 owns a tile of pixels and traces the whole ray
-// tree of its pixel-samples out of a wave-private LDS pool ("wavefront loop inside a wave").
+// rt_kernels.h — the render kernels: persistent waves that trace whole ray trees out of a wave-private
+// LDS pool ("wavefront path tracing inside a wave"), plus the resolve pass.
 //
 // Reference path: Scene.renderScene -> renderPass -> rayTraceBase -> rayTrace (Scene.fs:51-121).
 // The reference's estimator is a branching recursion  L = E + (1/n) * sum_i shading_i * L(child_i)
 // (Scene.fs:62-70).  It is evaluated here in its throughput form (cf. notes.txt:21-54): every
 // pending ray carries beta = prod shading/n along its path and adds beta*E to its pixel-sample
 // when it hits an emitter.  Per-ray arithmetic (intersection, hit point, scatter direction) is
-// bit-identical to the recursion; only the order of the final additions differs.
+// bit-identical to the recursion; only the final additions differ, and those are done in 32.32
+// fixed point, so the image does not depend on the order in which rays happen to be traced
+// (run-to-run, across wave counts and across multi-GPU partitions the output is bit-identical).
+//
+// Work distribution: pixel-samples are numbered 0..total-1 (sample-minor, then py, then column);
+// a wave pulls them in chunks of 64 from one global counter whenever its pool runs dry, so all waves
+// finish together whatever the cost of individual pixels (1 ray for a light, thousands for the floor).
 //
 // Pool: a LIFO of HIT RECORDS (hit point, incoming direction, beta, surface, tree node).  A record
 // with n children is expanded lazily: each iteration takes the top records whose children fit in
 // 64 lanes (ballot + prefix sum), every lane generates ONE child ray, intersects it against the
 // scene and, if the child hits a scattering surface, pushes one new record (ballot + prefix-sum
-// compaction).  Records stay sorted by tree level (deepest on top), which bounds the pool to
-// slots + 64 * levels records — see DESIGN.md "Pool bound".
+// compaction).  Lanes left over when the pool is drained start new pixel-samples (primary rays).
+// Records stay sorted by tree level (deepest on top), which bounds the pool to 64 records per
+// level — see DESIGN.md "Pool bound".
 #pragma once
 #include "rt_device.h"
 
 namespace rt {
 
-// Cold per-frame constants: only the primary-ray branch reads them.  The struct is the FIRST kernel
-// parameter and is read through an opaque pointer to the kernarg segment (cold_args() below), so that
-// the compiler neither keeps its ~30 values in SGPRs across the closest-hit loop nor spills them to
-// VGPR lanes there (measured: 14 v_readlane/v_writelane per surface test before this split).
+// Cold per-frame constants: only the primary-ray branch, the flush and the epilogue read them.  The
+// struct is the FIRST kernel parameter and is read through an opaque pointer to the kernarg segment
+// (cold_args() below), so that the compiler neither keeps its values in SGPRs across the closest-hit
+// loop nor spills them to VGPR lanes there (measured: 14 v_readlane/v_writelane per surface test
+// before this split).
 struct ColdArgs {
     float rot[9];                   // Rotation(cameraWS) rows (Scene.fs:100)
     float origin[3];                // cameraWS.Translation (Scene.fs:102)
@@ -31,8 +39,10 @@ struct ColdArgs {
     float bg[3];                    // backgroundColor (Scene.fs:32)
     int x_begin, x_step, jitter;
     int H, ncols;
-    int tw_log2, th_log2, ntx;      // pixel tile of one wave: 2^tw_log2 columns x 2^th_log2 rows
-    float* rgba;                    // [ncols*H*4]
+    unsigned long long total;       // pixel-samples of this launch = ncols * H * spp
+    unsigned int npix, scatter;     // hand-out order: pixel (i * scatter) mod npix, gcd(scatter, npix) = 1
+    unsigned long long* counter;    // next pixel-sample to hand out
+    unsigned long long* accum;      // [ncols*H*3] per-pixel radiance sums, 32.32 fixed point
     float* depth;                   // [ncols*H]
     unsigned long long* ids;        // [ncols*H] or null
     unsigned long long* stats;      // RT_STATS_WORDS u64, or null
@@ -42,8 +52,6 @@ struct ColdArgs {
 // Hot constants: live in SGPRs for the whole kernel.
 struct RenderArgs {
     int nsurf, spp, max_depth, bg_nonzero, cap;
-    int pix_per_group;              // pixels of one wave's tile
-    int passes;                     // ceil(spp / S) when spp > S, else 1
     uint32_t seed_lo, seed_hi;
 };
 
@@ -68,25 +76,42 @@ RT_DEV int mbcnt64(unsigned long long m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// S = pixel-sample slots one wave traces together (multiple of 64).
+// radiance contribution -> signed 32.32 fixed point (two's complement in a u64); |x| < 2^31
+RT_DEV unsigned long long to_fixed(float x)
+{
+    const float fl = floorf(x);
+    const float fr = x - fl;                                    // exact, in [0,1)
+    const uint32_t lo = (uint32_t)(fr * 4294967296.0f);         // exact scaling, truncating convert
+    const int32_t hi = (int32_t)fl;
+    return ((unsigned long long)(uint32_t)hi << 32) | lo;
+}
+
+constexpr int kSlots = 64;          // pixel-samples a wave can have in flight
+
+// LDS of one wave, in dwords: slot table, lane map, record pool
+constexpr int kLdsAcc = 0;                       // u64 [kSlots*3]  radiance of the pixel-sample, 32.32
+constexpr int kLdsPs = kLdsAcc + kSlots * 6;     // u64 [kSlots]    global pixel-sample index (RNG counter)
+constexpr int kLdsPix = kLdsPs + kSlots * 2;     // u32 [kSlots]    compact pixel index (k*H + py)
+constexpr int kLdsPend = kLdsPix + kSlots;       // u32 [kSlots]    records of this slot in the pool or in flight
+constexpr int kLdsMap = kLdsPend + kSlots;       // u32 [64]        lane map (children / slot allocation)
+constexpr int kLdsPool = kLdsMap + 64;           // records, in blocks of 64
+
 // NODE64 = keep the ray-tree node index in 64 bits (needed when max_trace_depth > 13).
-//
-// One iteration of the loop = 64 rays: lanes [0,nchild) each take one child of the records popped from
-// the top of the pool; when that pop empties the pool, the remaining lanes start fresh pixel-samples
-// (primary rays), so every iteration is full until the wave runs out of slots.
-template <int S, bool NODE64>
-__global__ __launch_bounds__(64) void render_kernel(const ColdArgs cold_unused, const RenderArgs a,
-                                                    const GeomRec* __restrict__ geom,
-                                                    const ShadeRec* __restrict__ shade)
+template <bool NODE64>
+__global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, const RenderArgs a,
+                                                   const GeomRec* __restrict__ geom,
+                                                   const ShadeRec* __restrict__ shade)
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
     const int cap = a.cap;
     constexpr int NF = NODE64 ? 12 : 11;
-    float* acc = reinterpret_cast<float*>(smem);                      // [S*3] radiance per slot
-    uint64_t* slot_ps = reinterpret_cast<uint64_t*>(smem + S * 3);    // [S] pixel-sample index (RNG counter)
-    uint32_t* map = smem + S * 5;                                     // [64] child lane -> (record offset, child)
-    uint32_t* pool = map + 64;                                        // records, in blocks of 64
+    unsigned long long* sl_acc = reinterpret_cast<unsigned long long*>(smem + kLdsAcc);
+    unsigned long long* sl_ps = reinterpret_cast<unsigned long long*>(smem + kLdsPs);
+    uint32_t* sl_pix = smem + kLdsPix;
+    uint32_t* sl_pend = smem + kLdsPend;
+    uint32_t* map = smem + kLdsMap;
+    uint32_t* pool = smem + kLdsPool;
     // Record r lives in block r/64: field f of record r is the dword pool[(r/64)*NF*64 + f*64 + r%64], so a
     // field is an immediate offset (f*256 bytes) from the record's base address and lanes reading
     // consecutive records hit consecutive banks.
@@ -95,271 +120,286 @@ __global__ __launch_bounds__(64) void render_kernel(const ColdArgs cold_unused, 
            F_META = 576, F_NODE = 640, F_NODEHI = 704 };
 
     const int spp = a.spp;
+    const unsigned long long t_start = __builtin_readcyclecounter();
 
-    // ---- this wave's pixel tile ------------------------------------------------------------
-    const int G = a.pix_per_group;
-
-    int top = 0;                        // records in the pool (wave-uniform)
-    uint32_t nrays = 0;                 // closest-hit queries by this lane
+    int top = 0;                                // records in the pool (wave-uniform)
+    unsigned long long freemask = ~0ull;        // free slots (wave-uniform)
+    unsigned long long res_next = 0;            // first pixel-sample of the current refill
+    bool exhausted = false;                     // the global counter has run past the end
+    uint32_t nrays = 0;                         // closest-hit queries by this lane
     float maxd = 0.0f;
     bool overflow = false;
-    uint32_t n_iter = 0, n_prim_iter = 0;   // diagnostics (wave-uniform)
-    f3 pixsum = F3(0.0f, 0.0f, 0.0f);   // carried across passes only when G == 1
+    uint32_t n_iter = 0, n_prim_iter = 0;       // diagnostics (wave-uniform)
+    int spins = 0;
 
-    for (int pass = 0; pass < a.passes; pass++) {
-        const int nslots = (spp <= S) ? G * spp : min(S, spp - pass * S);
-        for (int i = lane; i < nslots * 3; i += 64) acc[i] = 0.0f;
-        int next = 0;                   // next slot to start (wave-uniform)
-        __syncthreads();
-
-        while (true) {
-            // ---- take the top records whose children fit in 64 lanes (prefix sum over ballots)
-            int nchild = 0;
-            uint32_t mp = 0u;
-            const int top0 = top;
-            if (top > 0) {
-                const int ridx = top - 1 - lane;
-                const uint32_t rmeta = (ridx >= 0) ? rec_base(ridx)[F_META] : 0u;
-                const int rn = (rmeta >> 13) & 7;
-                const unsigned long long b0 = __ballot(rn & 1), b1 = __ballot(rn & 2), b2 = __ballot(rn & 4);
-                const int excl = mbcnt64(b0) + 2 * mbcnt64(b1) + 4 * mbcnt64(b2);
-                const bool take = rn > 0 && excl + rn <= 64;
-                const unsigned long long tk = __ballot(take);
-                nchild = __popcll(b0 & tk) + 2 * __popcll(b1 & tk) + 4 * __popcll(b2 & tk);
-                if (take)
-                    for (int c = 0; c < rn; c++) map[excl + c] = (uint32_t)(lane * 4 + c);
-                __syncthreads();
-                if (lane < nchild) mp = map[lane];
-                top -= __popcll(tk);
-            }
-            // ---- the pool is drained: start new pixel-samples in the free lanes
-            const int nprim = (top == 0) ? min(64 - nchild, nslots - next) : 0;
-            if (nchild + nprim == 0) break;
-            n_iter++; n_prim_iter += (nprim > 0) ? 1u : 0u;
-            const bool is_child = lane < nchild;
-            const bool is_prim = !is_child && lane < nchild + nprim;
-
-            f3 O = F3(0, 0, 0), Dn = F3(0, 0, 0), beta = F3(1.0f, 1.0f, 1.0f);
-            int slot = 0, clevel = 0; uint64_t cnode = 0;
-            bool alive = false;         // this lane intersects a ray
-            float dot_view = 1.0f; int prim_k = 0, prim_py = 0; bool prim_first = false;
-
-            if (nprim > 0 && is_prim) {
-                // ============ rayTraceBase: primary ray (Camera.fs:8-39, Scene.fs:98-102) ============
-                slot = next + (lane - nchild);
-                int p, s;
-                if (spp <= S) { p = slot / spp; s = slot - p * spp; }
-                else          { p = 0; s = pass * S + slot; }
-                const ColdArgs* ca = cold_args();
-                const int tx = (int)blockIdx.x % ca->ntx, ty = (int)blockIdx.x / ca->ntx;
-                const int k = (tx << ca->tw_log2) + (p & ((1 << ca->tw_log2) - 1));
-                const int py = (ty << ca->th_log2) + (p >> ca->tw_log2);
-                if (k < ca->ncols && py < ca->H) {
-                    const int px = ca->x_begin + k * ca->x_step;
-                    const uint64_t pixel = (uint64_t)px * (uint64_t)ca->H + (uint64_t)py;
-                    slot_ps[slot] = pixel * (uint64_t)spp + (uint64_t)s;
-                    f3 rv = F3(0.0f, 0.0f, 0.0f);
-                    if (ca->jitter) rv = unit_sphere_sample(a.seed_lo, a.seed_hi, pixel);
-                    const float fw = ca->fw, fh = ca->fh, tan_half = ca->tan_half;
-                    float xoff = rv.x / fw, yoff = rv.y / fh;
-                    float pxp = ((float)px + 0.5f) + xoff, pyp = ((float)py + 0.5f) + yoff;
-                    float xn = pxp / fw, yn = pyp / fh;
-                    float xs = 2.0f * xn - 1.0f, ys = 1.0f - 2.0f * yn;
-                    float xc = xs * ca->aspect * tan_half, yc = ys * tan_half;
-                    f3 dirCS = normalize(F3(xc, yc, -1.0f));
-                    f3 dirT = F3((dirCS.x * ca->rot[0] + dirCS.y * ca->rot[3]) + dirCS.z * ca->rot[6],
-                                 (dirCS.x * ca->rot[1] + dirCS.y * ca->rot[4]) + dirCS.z * ca->rot[7],
-                                 (dirCS.x * ca->rot[2] + dirCS.y * ca->rot[5]) + dirCS.z * ca->rot[8]);
-                    Dn = make_ray_dir(normalize(dirT));
-                    O = F3(ca->origin[0], ca->origin[1], ca->origin[2]);
-                    dot_view = dot(F3(ca->look_n[0], ca->look_n[1], ca->look_n[2]), Dn);   // Scene.fs:76
-                    alive = true;
-                    prim_k = k; prim_py = py; prim_first = (s == 0);
-                }
-            }
-            next += nprim;
-
-            if (is_child) {
-                // ============ rayTrace: one child of a popped record (Scene.fs:62-70) ============
-                const int rec = top0 - 1 - (int)(mp >> 2);
-                const int child = (int)(mp & 3);
-                const uint32_t* rb = rec_base(rec);
-                O = F3(__uint_as_float(rb[F_PX]), __uint_as_float(rb[F_PY]), __uint_as_float(rb[F_PZ]));
-                const f3 Din = F3(__uint_as_float(rb[F_DX]), __uint_as_float(rb[F_DY]), __uint_as_float(rb[F_DZ]));
-                const f3 pbeta = F3(__uint_as_float(rb[F_BX]), __uint_as_float(rb[F_BY]), __uint_as_float(rb[F_BZ]));
-                const uint32_t meta = rb[F_META];
-                uint64_t node = rb[F_NODE];
-                if (NODE64) node |= (uint64_t)rb[F_NODEHI] << 32;
-                slot = meta & 0xff;
-                const int level = (meta >> 8) & 31, n = (meta >> 13) & 7;
-                const int kind = (meta >> 16) & 3, gty = (meta >> 18) & 3;
-                const uint32_t surf = meta >> 20;
-                clevel = level + 1;
-                cnode = 4ull * node + (uint64_t)child + 1ull;
-                const uint64_t ps = slot_ps[slot];                    // the RNG counter
-
-                const ShadeRec* sr = shade + surf;
-                const float4 al = *reinterpret_cast<const float4*>(&sr->albedo[0]);
-                const float4 nc = *reinterpret_cast<const float4*>(&sr->nc[0]);
-                const f3 albedo = F3(al.x, al.y, al.z);
-
-                // Hitable.NormalForSurfacePoint: Sphere.fs:37-38, Plane.fs:50-51
-                f3 normal = F3(nc.x, nc.y, nc.z);
-                if (gty == kGeomSphere) normal = normalize(O - normal);
-
-                alive = true;
-                f3 shd;                 // shading_i; folded into beta below
-                float inv_n;
-                if (kind == kKindDielectric) {
-                    // Surface.fs:124-153 CalcFresnel + :168-181 GenerateSamples
-                    normal = normalize(normal);
-                    const f3 refl = normalize(reflect(Din, normal));
-                    float eta_i, eta_t; f3 fn;
-                    if (dot(Din, normal) > 0.0f) { eta_i = al.w; eta_t = 1.0f; fn = neg(normal); }
-                    else                         { eta_i = 1.0f; eta_t = al.w; fn = normal; }
-                    const float cos_i = dot(Din, neg(fn));
-                    const float eta = div_rn(eta_i, eta_t);
-                    const float disc = 1.0f - (eta * eta) * (1.0f - (cos_i * cos_i));
-                    const bool refracted = disc > 0.0f;
-                    float F = 1.0f;
-                    if (refracted) {
-                        const float q = div_rn(eta_t - eta_i, eta_t + eta_i);
-                        const float R0 = q * q;
-                        F = R0 + (1.0f - R0) * pow5(1.0f - cos_i);
-                    }
-                    const bool single = rounds_to(F, 1e3f, 1e3f);      // Round(F,3) = 1
-                    if (child == 0) {
-                        Dn = make_ray_dir(refl);
-                        shd = albedo * F;                      // (2*albedo*F)/2 == albedo*F exactly
-                    } else {
-                        alive = !single;
-                        const f3 q = (Din + fn * cos_i) * eta - fn * sqrt_rn(disc);
-                        Dn = make_ray_dir(normalize(q));
-                        shd = albedo * (1.0f - F);
-                    }
-                    inv_n = 1.0f;
-                } else {
-                    // Lambertian.Scatter (Surface.fs:66-83) / Metal.Scatter (Surface.fs:93-109)
-                    if (kind == kKindMetal) normal = normalize(normal);
-                    const f3 rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode);
-                    f3 nt, nb;
-                    frame_around(normal, nt, nb);
-                    // Vector4.Transform(rn, ChangeOfBase nt n nb): rows nt, n, nb; M4x = 0
-                    const f3 ns = F3(((rn.x * nt.x + rn.y * normal.x) + rn.z * nb.x) + 0.0f,
-                                     ((rn.x * nt.y + rn.y * normal.y) + rn.z * nb.y) + 0.0f,
-                                     ((rn.x * nt.z + rn.y * normal.z) + rn.z * nb.z) + 0.0f);
-                    if (kind == kKindLambert) {
-                        Dn = make_ray_dir(normalize(ns));
-                        const float pdf = 1.0f / (2.0f * 3.14159265358979323846f);
-                        const f3 brdf = divs(albedo, 3.14159265358979323846f);
-                        shd = brdf * div_rn(rn.y, pdf);
-                    } else {
-                        const float fuzz = al.w;
-                        const f3 mod = normalize(normal * (1.0f - fuzz) + ns * fuzz);
-                        Dn = make_ray_dir(normalize(reflect(Din, mod)));
-                        shd = albedo * (1.0f / 1.0f);
-                    }
-                    inv_n = div_rn(1.0f, (float)n);
-                }
-                beta = (pbeta * shd) * inv_n;
-
-                if (alive && clevel > a.max_depth + 1) {
-                    // depth guard (Scene.fs:52-54): the child returns backgroundColor unintersected
-                    alive = false;
-                    const ColdArgs* ca = cold_args();
-                    atomicAdd(&acc[slot * 3 + 0], beta.x * ca->bg[0]);
-                    atomicAdd(&acc[slot * 3 + 1], beta.y * ca->bg[1]);
-                    atomicAdd(&acc[slot * 3 + 2], beta.z * ca->bg[2]);
-                }
-            }
-
-            // ============ findClosestIntersection + hit handling, all 64 lanes ============
-            bool push = false;
-            f3 P = F3(0, 0, 0);
-            int hidx = -1; uint32_t hinfo = 0;
-            if (alive) {
-                float t;
-                closest_hit(geom, a.nsurf, O, Dn, hidx, t);
-                nrays++;
-                bool hit = hidx >= 0;
-                float4 em = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (hit) {
-                    em = *reinterpret_cast<const float4*>(&shade[hidx].emission[0]);
-                    hinfo = __float_as_uint(em.w);
-                    // Scene.fs:79: the primary's closest candidate is re-tested with dotView; planes then
-                    // cull at TMax/dotView (Plane.fs:46).  A failed re-test is a miss, not the next hit.
-                    if (is_prim && ((hinfo >> 5) & 3) != kGeomSphere) hit = t <= (kTMax / dot_view);
-                }
-                if (is_prim && prim_first) {                               // Scene.fs:80 / :29
-                    const ColdArgs* ca = cold_args();
-                    const size_t o = (size_t)prim_k * (size_t)ca->H + (size_t)prim_py;
-                    ca->depth[o] = hit ? t : kFltMax;
-                    if (ca->ids) ca->ids[o] = hit ? shade[hidx].id : 0ull;
-                    if (hit) maxd = fmaxf(maxd, t);
-                }
-                if (hit) {
-                    if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
-                        atomicAdd(&acc[slot * 3 + 0], beta.x * em.x);
-                        atomicAdd(&acc[slot * 3 + 1], beta.y * em.y);
-                        atomicAdd(&acc[slot * 3 + 2], beta.z * em.z);
-                    }
-                    const int hn = (hinfo >> 2) & 7;
-                    // children of a hit at level max_depth+1 are all cut by the depth guard; with a black
-                    // background they contribute exactly 0 and are skipped
-                    push = hn > 0 && (clevel <= a.max_depth || a.bg_nonzero);
-                    P = O + Dn * t;                                        // Core.fs:59
-                } else if (a.bg_nonzero) {
-                    const ColdArgs* ca = cold_args();
-                    atomicAdd(&acc[slot * 3 + 0], beta.x * ca->bg[0]);
-                    atomicAdd(&acc[slot * 3 + 1], beta.y * ca->bg[1]);
-                    atomicAdd(&acc[slot * 3 + 2], beta.z * ca->bg[2]);
-                }
-            }
-            // ---- compaction: hits on scattering surfaces become records, deepest on top
-            const unsigned long long pm = __ballot(push);
-            const int npush = __popcll(pm);
-            if (top + npush > cap) { overflow = true; }
-            else {
-                if (push) {
-                    const int pos = top + (npush - 1 - mbcnt64(pm));
-                    uint32_t* wb = rec_base(pos);
-                    wb[F_PX] = __float_as_uint(P.x); wb[F_PY] = __float_as_uint(P.y); wb[F_PZ] = __float_as_uint(P.z);
-                    wb[F_DX] = __float_as_uint(Dn.x); wb[F_DY] = __float_as_uint(Dn.y); wb[F_DZ] = __float_as_uint(Dn.z);
-                    wb[F_BX] = __float_as_uint(beta.x); wb[F_BY] = __float_as_uint(beta.y); wb[F_BZ] = __float_as_uint(beta.z);
-                    wb[F_META] = make_meta(slot, clevel, (hinfo >> 2) & 7, hinfo & 3, (hinfo >> 5) & 3, hidx);
-                    wb[F_NODE] = (uint32_t)cnode;
-                    if (NODE64) wb[F_NODEHI] = (uint32_t)(cnode >> 32);
-                }
-                top += npush;
-            }
+    while (true) {
+        // ---- take the top records whose children fit in 64 lanes (prefix sum over ballots)
+        int nchild = 0;
+        uint32_t mp = 0u;
+        const int top0 = top;
+        if (top > 0) {
+            const int ridx = top - 1 - lane;
+            const uint32_t rmeta = (ridx >= 0) ? rec_base(ridx)[F_META] : 0u;
+            const int rn = (rmeta >> 13) & 7;
+            const unsigned long long b0 = __ballot(rn & 1), b1 = __ballot(rn & 2), b2 = __ballot(rn & 4);
+            const int excl = mbcnt64(b0) + 2 * mbcnt64(b1) + 4 * mbcnt64(b2);
+            const bool take = rn > 0 && excl + rn <= 64;
+            const unsigned long long tk = __ballot(take);
+            nchild = __popcll(b0 & tk) + 2 * __popcll(b1 & tk) + 4 * __popcll(b2 & tk);
+            if (take)
+                for (int c = 0; c < rn; c++) map[excl + c] = (uint32_t)(lane * 4 + c);
             __syncthreads();
+            if (lane < nchild) mp = map[lane];
+            top -= __popcll(tk);
+            __syncthreads();                    // map is reused for the slot allocation below
+        }
+        // ---- the pool is drained: start new pixel-samples in the free lanes
+        int nprim = 0;
+        if (top == 0 && nchild < 64 && !exhausted) {
+            // pull exactly as many pixel-samples as there are free lanes (and free slots): one returning
+            // atomic per refill keeps the hand-out fine-grained, so no wave is left holding a queue of
+            // expensive pixels while the others have finished
+            const int want = min(64 - nchild, __popcll(freemask));
+            if (want > 0) {
+                const ColdArgs* ca = cold_args();
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(ca->counter, (unsigned long long)want);
+                base = __shfl(base, 0);
+                const unsigned long long total = ca->total;
+                if (base >= total) exhausted = true;
+                else { res_next = base; nprim = (base + (unsigned long long)want <= total) ? want : (int)(total - base); }
+            }
+        }
+        if (nchild + nprim == 0) {
+            if (exhausted) break;               // nothing in the pool, nothing left to start
+            if (++spins > 4) { overflow = true; break; }   // cannot happen (all slots are free here): never spin
+            continue;
+        }
+        n_iter++; n_prim_iter += (nprim > 0) ? 1u : 0u; spins = 0;
+        const bool is_child = lane < nchild;
+        const bool is_prim = !is_child && lane < nchild + nprim;
+
+        f3 O = F3(0, 0, 0), Dn = F3(0, 0, 0), beta = F3(1.0f, 1.0f, 1.0f);
+        int slot = 0, clevel = 0; uint64_t cnode = 0;
+        bool alive = false;                     // this lane intersects a ray
+        bool owner = false;                     // this lane retires one pending unit of its slot
+        float dot_view = 1.0f; uint32_t prim_o = 0; bool prim_first = false;
+
+        if (nprim > 0) {
+            // ---- slot allocation: the lane whose index is a free slot number offers it by rank
+            const bool offer = ((freemask >> lane) & 1ull) != 0 && mbcnt64(freemask) < nprim;
+            if (offer) map[mbcnt64(freemask)] = (uint32_t)lane;
+            freemask &= ~__ballot(offer);
+            __syncthreads();
+            if (is_prim) {
+                // ============ rayTraceBase: primary ray (Camera.fs:8-39, Scene.fs:98-102) ============
+                const ColdArgs* ca = cold_args();
+                slot = (int)map[lane - nchild];
+                const unsigned long long q = res_next + (unsigned long long)(lane - nchild);   // compact index
+                const unsigned long long o64 = q / (unsigned long long)spp;
+                const int s = (int)(q - o64 * (unsigned long long)spp);
+                // Consecutive hand-outs go to pixels far apart in the image (a fixed bijection), so that every
+                // refill mixes cheap and expensive pixels: with row-major hand-out one wave would start on 64
+                // neighbouring floor pixels (thousands of rays each) and finish long after the others.
+                const uint32_t o = (uint32_t)((o64 * (unsigned long long)ca->scatter) % (unsigned long long)ca->npix);
+                const int k = (int)(o / (uint32_t)ca->H), py = (int)(o - (uint32_t)k * (uint32_t)ca->H);
+                const int px = ca->x_begin + k * ca->x_step;
+                const uint64_t pixel = (uint64_t)px * (uint64_t)ca->H + (uint64_t)py;
+                sl_ps[slot] = pixel * (uint64_t)spp + (uint64_t)s;
+                sl_pix[slot] = o;
+                sl_pend[slot] = 1u;
+                sl_acc[slot * 3 + 0] = 0ull; sl_acc[slot * 3 + 1] = 0ull; sl_acc[slot * 3 + 2] = 0ull;
+                f3 rv = F3(0.0f, 0.0f, 0.0f);
+                if (ca->jitter) rv = unit_sphere_sample(a.seed_lo, a.seed_hi, pixel);
+                const float fw = ca->fw, fh = ca->fh, tan_half = ca->tan_half;
+                float xoff = rv.x / fw, yoff = rv.y / fh;
+                float pxp = ((float)px + 0.5f) + xoff, pyp = ((float)py + 0.5f) + yoff;
+                float xn = pxp / fw, yn = pyp / fh;
+                float xs = 2.0f * xn - 1.0f, ys = 1.0f - 2.0f * yn;
+                float xc = xs * ca->aspect * tan_half, yc = ys * tan_half;
+                f3 dirCS = normalize(F3(xc, yc, -1.0f));
+                f3 dirT = F3((dirCS.x * ca->rot[0] + dirCS.y * ca->rot[3]) + dirCS.z * ca->rot[6],
+                             (dirCS.x * ca->rot[1] + dirCS.y * ca->rot[4]) + dirCS.z * ca->rot[7],
+                             (dirCS.x * ca->rot[2] + dirCS.y * ca->rot[5]) + dirCS.z * ca->rot[8]);
+                Dn = make_ray_dir(normalize(dirT));
+                O = F3(ca->origin[0], ca->origin[1], ca->origin[2]);
+                dot_view = dot(F3(ca->look_n[0], ca->look_n[1], ca->look_n[2]), Dn);   // Scene.fs:76
+                alive = true; owner = true;
+                prim_o = o; prim_first = (s == 0);
+            }
         }
 
-        // ====== per-pixel sum over samples in sample order, mean, gamma 2 (Scene.fs:109,114) ======
-        {
-            const int cnt = (spp <= S) ? spp : min(S, spp - pass * S);
-            const ColdArgs* ca = cold_args();
-            const int tx = (int)blockIdx.x % ca->ntx, ty = (int)blockIdx.x / ca->ntx;
-            for (int pb = 0; pb < G; pb += 64) {
-                const int p = pb + lane;
-                if (p < G) {
-                    const int base = (spp <= S) ? p * spp : 0;
-                    f3 sum = pixsum;
-                    for (int i = 0; i < cnt; i++) {
-                        const f3 c = F3(acc[(base + i) * 3 + 0], acc[(base + i) * 3 + 1], acc[(base + i) * 3 + 2]);
-                        sum = (pass == 0 && i == 0) ? c : sum + c;
-                    }
-                    pixsum = sum;
-                    const int k = (tx << ca->tw_log2) + (p & ((1 << ca->tw_log2) - 1));
-                    const int py = (ty << ca->th_log2) + (p >> ca->tw_log2);
-                    if (pass == a.passes - 1 && k < ca->ncols && py < ca->H) {
-                        const f3 avg = divs(sum, (float)spp);
-                        const size_t o = (size_t)k * (size_t)ca->H + (size_t)py;
-                        *reinterpret_cast<float4*>(ca->rgba + 4 * o) =
-                            make_float4(sqrtf(avg.x), sqrtf(avg.y), sqrtf(avg.z), 1.0f);
-                    }
+        if (is_child) {
+            // ============ rayTrace: one child of a popped record (Scene.fs:62-70) ============
+            const int rec = top0 - 1 - (int)(mp >> 2);
+            const int child = (int)(mp & 3);
+            const uint32_t* rb = rec_base(rec);
+            O = F3(__uint_as_float(rb[F_PX]), __uint_as_float(rb[F_PY]), __uint_as_float(rb[F_PZ]));
+            const f3 Din = F3(__uint_as_float(rb[F_DX]), __uint_as_float(rb[F_DY]), __uint_as_float(rb[F_DZ]));
+            const f3 pbeta = F3(__uint_as_float(rb[F_BX]), __uint_as_float(rb[F_BY]), __uint_as_float(rb[F_BZ]));
+            const uint32_t meta = rb[F_META];
+            uint64_t node = rb[F_NODE];
+            if (NODE64) node |= (uint64_t)rb[F_NODEHI] << 32;
+            slot = meta & 0xff;
+            const int level = (meta >> 8) & 31, n = (meta >> 13) & 7;
+            const int kind = (meta >> 16) & 3, gty = (meta >> 18) & 3;
+            const uint32_t surf = meta >> 20;
+            clevel = level + 1;
+            cnode = 4ull * node + (uint64_t)child + 1ull;
+            const uint64_t ps = sl_ps[slot];                      // the RNG counter
+            owner = (child == 0);
+
+            const ShadeRec* sr = shade + surf;
+            const float4 al = *reinterpret_cast<const float4*>(&sr->albedo[0]);
+            const float4 nc = *reinterpret_cast<const float4*>(&sr->nc[0]);
+            const f3 albedo = F3(al.x, al.y, al.z);
+
+            // Hitable.NormalForSurfacePoint: Sphere.fs:37-38, Plane.fs:50-51
+            f3 normal = F3(nc.x, nc.y, nc.z);
+            if (gty == kGeomSphere) normal = normalize(O - normal);
+
+            alive = true;
+            f3 shd;                 // shading_i; folded into beta below
+            float inv_n;
+            if (kind == kKindDielectric) {
+                // Surface.fs:124-153 CalcFresnel + :168-181 GenerateSamples
+                normal = normalize(normal);
+                const f3 refl = normalize(reflect(Din, normal));
+                float eta_i, eta_t; f3 fn;
+                if (dot(Din, normal) > 0.0f) { eta_i = al.w; eta_t = 1.0f; fn = neg(normal); }
+                else                         { eta_i = 1.0f; eta_t = al.w; fn = normal; }
+                const float cos_i = dot(Din, neg(fn));
+                const float eta = div_rn(eta_i, eta_t);
+                const float disc = 1.0f - (eta * eta) * (1.0f - (cos_i * cos_i));
+                const bool refracted = disc > 0.0f;
+                float F = 1.0f;
+                if (refracted) {
+                    const float q = div_rn(eta_t - eta_i, eta_t + eta_i);
+                    const float R0 = q * q;
+                    F = R0 + (1.0f - R0) * pow5(1.0f - cos_i);
                 }
+                const bool single = rounds_to(F, 1e3f, 1e3f);      // Round(F,3) = 1
+                if (child == 0) {
+                    Dn = make_ray_dir(refl);
+                    shd = albedo * F;                      // (2*albedo*F)/2 == albedo*F exactly
+                } else {
+                    alive = !single;
+                    const f3 q = (Din + fn * cos_i) * eta - fn * sqrt_rn(disc);
+                    Dn = make_ray_dir(normalize(q));
+                    shd = albedo * (1.0f - F);
+                }
+                inv_n = 1.0f;
+            } else {
+                // Lambertian.Scatter (Surface.fs:66-83) / Metal.Scatter (Surface.fs:93-109)
+                if (kind == kKindMetal) normal = normalize(normal);
+                const f3 rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode);
+                f3 nt, nb;
+                frame_around(normal, nt, nb);
+                // Vector4.Transform(rn, ChangeOfBase nt n nb): rows nt, n, nb; M4x = 0
+                const f3 ns = F3(((rn.x * nt.x + rn.y * normal.x) + rn.z * nb.x) + 0.0f,
+                                 ((rn.x * nt.y + rn.y * normal.y) + rn.z * nb.y) + 0.0f,
+                                 ((rn.x * nt.z + rn.y * normal.z) + rn.z * nb.z) + 0.0f);
+                if (kind == kKindLambert) {
+                    Dn = make_ray_dir(normalize(ns));
+                    const float pdf = 1.0f / (2.0f * 3.14159265358979323846f);
+                    const f3 brdf = divs(albedo, 3.14159265358979323846f);
+                    shd = brdf * div_rn(rn.y, pdf);
+                } else {
+                    const float fuzz = al.w;
+                    const f3 mod = normalize(normal * (1.0f - fuzz) + ns * fuzz);
+                    Dn = make_ray_dir(normalize(reflect(Din, mod)));
+                    shd = albedo * (1.0f / 1.0f);
+                }
+                inv_n = div_rn(1.0f, (float)n);
             }
+            beta = (pbeta * shd) * inv_n;
+
+            if (alive && clevel > a.max_depth + 1) {
+                // depth guard (Scene.fs:52-54): the child returns backgroundColor unintersected
+                alive = false;
+                const ColdArgs* ca = cold_args();
+                atomicAdd(&sl_acc[slot * 3 + 0], to_fixed(beta.x * ca->bg[0]));
+                atomicAdd(&sl_acc[slot * 3 + 1], to_fixed(beta.y * ca->bg[1]));
+                atomicAdd(&sl_acc[slot * 3 + 2], to_fixed(beta.z * ca->bg[2]));
+            }
+        }
+
+        // ============ findClosestIntersection + hit handling, all 64 lanes ============
+        bool push = false;
+        f3 P = F3(0, 0, 0);
+        int hidx = -1; uint32_t hinfo = 0;
+        if (alive) {
+            float t;
+            closest_hit(geom, a.nsurf, O, Dn, hidx, t);
+            nrays++;
+            bool hit = hidx >= 0;
+            float4 em = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (hit) {
+                em = *reinterpret_cast<const float4*>(&shade[hidx].emission[0]);
+                hinfo = __float_as_uint(em.w);
+                // Scene.fs:79: the primary's closest candidate is re-tested with dotView; planes then
+                // cull at TMax/dotView (Plane.fs:46).  A failed re-test is a miss, not the next hit.
+                if (is_prim && ((hinfo >> 5) & 3) != kGeomSphere) hit = t <= (kTMax / dot_view);
+            }
+            if (is_prim && prim_first) {                               // Scene.fs:80 / :29
+                const ColdArgs* ca = cold_args();
+                ca->depth[prim_o] = hit ? t : kFltMax;
+                if (ca->ids) ca->ids[prim_o] = hit ? shade[hidx].id : 0ull;
+                if (hit) maxd = fmaxf(maxd, t);
+            }
+            if (hit) {
+                if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
+                    atomicAdd(&sl_acc[slot * 3 + 0], to_fixed(beta.x * em.x));
+                    atomicAdd(&sl_acc[slot * 3 + 1], to_fixed(beta.y * em.y));
+                    atomicAdd(&sl_acc[slot * 3 + 2], to_fixed(beta.z * em.z));
+                }
+                const int hn = (hinfo >> 2) & 7;
+                // children of a hit at level max_depth+1 are all cut by the depth guard; with a black
+                // background they contribute exactly 0 and are skipped
+                push = hn > 0 && (clevel <= a.max_depth || a.bg_nonzero);
+                P = O + Dn * t;                                        // Core.fs:59
+            } else if (a.bg_nonzero) {
+                const ColdArgs* ca = cold_args();
+                atomicAdd(&sl_acc[slot * 3 + 0], to_fixed(beta.x * ca->bg[0]));
+                atomicAdd(&sl_acc[slot * 3 + 1], to_fixed(beta.y * ca->bg[1]));
+                atomicAdd(&sl_acc[slot * 3 + 2], to_fixed(beta.z * ca->bg[2]));
+            }
+        }
+        // ---- compaction: hits on scattering surfaces become records, deepest on top
+        const unsigned long long pm = __ballot(push);
+        const int npush = __popcll(pm);
+        if (top + npush > cap) { overflow = true; }
+        else {
+            if (push) {
+                const int pos = top + (npush - 1 - mbcnt64(pm));
+                uint32_t* wb = rec_base(pos);
+                wb[F_PX] = __float_as_uint(P.x); wb[F_PY] = __float_as_uint(P.y); wb[F_PZ] = __float_as_uint(P.z);
+                wb[F_DX] = __float_as_uint(Dn.x); wb[F_DY] = __float_as_uint(Dn.y); wb[F_DZ] = __float_as_uint(Dn.z);
+                wb[F_BX] = __float_as_uint(beta.x); wb[F_BY] = __float_as_uint(beta.y); wb[F_BZ] = __float_as_uint(beta.z);
+                wb[F_META] = make_meta(slot, clevel, (hinfo >> 2) & 7, hinfo & 3, (hinfo >> 5) & 3, hidx);
+                wb[F_NODE] = (uint32_t)cnode;
+                if (NODE64) wb[F_NODEHI] = (uint32_t)(cnode >> 32);
+                atomicAdd(&sl_pend[slot], 1u);
+            }
+            top += npush;
+        }
+        // ---- retire: every popped record and every primary gives back one pending unit of its slot
+        //      (after this iteration's pushes, so the count reaches 0 only when the whole tree is done)
+        bool done = false;
+        if (owner) done = atomicSub(&sl_pend[slot], 1u) == 1u;
+        if (done) {
+            // the pixel-sample is complete: add it to its pixel (order-independent integer adds)
+            const ColdArgs* ca = cold_args();
+            unsigned long long* dst = ca->accum + (size_t)sl_pix[slot] * 3;
+            atomicAdd(dst + 0, sl_acc[slot * 3 + 0]);
+            atomicAdd(dst + 1, sl_acc[slot * 3 + 1]);
+            atomicAdd(dst + 2, sl_acc[slot * 3 + 2]);
+        }
+        unsigned long long dm = __ballot(done);
+        while (dm) {
+            const int l = __builtin_ctzll(dm);
+            dm &= dm - 1;
+            freemask |= 1ull << __builtin_amdgcn_readlane(slot, l);
         }
         __syncthreads();
     }
@@ -380,9 +420,30 @@ __global__ __launch_bounds__(64) void render_kernel(const ColdArgs cold_unused, 
             atomicMax(reinterpret_cast<unsigned int*>(stats + 1), __float_as_uint(m));
             atomicAdd(stats + 2, (unsigned long long)n_iter);
             atomicAdd(stats + 3, (unsigned long long)n_prim_iter);
+            atomicMax(stats + 4, (unsigned long long)n_iter);
+            const unsigned long long dt = __builtin_readcyclecounter() - t_start;
+            atomicMax(stats + 5, dt);
+            atomicAdd(stats + 6, dt);
+            atomicAdd(stats + 7, 1ull);
         }
     }
     if (overflow && lane == 0) atomicExch(ca->status, 1);
+}
+
+// Scene.fs:109,114: mean over samples, gamma 2, alpha 1.  One thread per pixel.
+__global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* __restrict__ accum, float* __restrict__ rgba,
+                                                      long long npix, int spp)
+{
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= npix) return;
+    float c[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float sum = (float)((double)(long long)accum[o * 3 + ch] * 0x1p-32);   // one rounding
+        c[ch] = sum;
+    }
+    const f3 avg = divs(F3(c[0], c[1], c[2]), (float)spp);
+    *reinterpret_cast<float4*>(rgba + 4 * o) = make_float4(sqrtf(avg.x), sqrtf(avg.y), sqrtf(avg.z), 1.0f);
 }
 
 // findClosestIntersection as a batch query (Surface.fs:49-58): one ray per thread.

@@ -58,9 +58,9 @@ def test_trace_depths(depth):
     _compare(Scene(width=96, height=64, samplesPerPixel=1, maxTraceDepth=depth, jitter=1, seed=3))
 
 
-@pytest.mark.parametrize("slots", [64, 128, 256])
-def test_slots_per_wave(slots):
-    _compare(Scene(width=100, height=75, samplesPerPixel=2, maxTraceDepth=4, jitter=1, seed=5, slots_per_wave=slots))
+@pytest.mark.parametrize("waves", [1, 3])
+def test_waves_per_cu(waves):
+    _compare(Scene(width=100, height=75, samplesPerPixel=2, maxTraceDepth=4, jitter=1, seed=5, waves_per_cu=waves))
 
 
 @pytest.mark.parametrize("lamb", [1, 2, 3])
@@ -92,10 +92,9 @@ def test_empty_scene():
 
 
 def test_column_partition_matches_full_frame():
-    """The multi-GPU partition: interleaved columns rendered separately equal the full frame.  Below 64
-    spp a wave's pixel tile depends on the partition, which reorders the f32 additions of a pixel
-    (last-bit differences); at >= 64 spp a wave owns one pixel and the partition is bit-exact."""
-    _partition_check(4, 1e-6)
+    """The multi-GPU partition: interleaved columns rendered separately equal the full frame bit for bit
+    (radiance is summed in fixed point, so the result does not depend on which wave traced what)."""
+    _partition_check(4, 0.0)
     _partition_check(64, 0.0)
 
 
