@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c4s", choices=sorted(WORKLOADS))
     ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--pool-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -99,7 +100,7 @@ def main():
 
     def make(wl):
         cfg = WORKLOADS[wl]
-        sc = Scene(device=local_rank, waves_per_cu=args.waves_per_cu, **cfg)
+        sc = Scene(device=local_rank, waves_per_cu=args.waves_per_cu, pool_blocks=args.pool_blocks, **cfg)
         xb, xe, xs, ncols = multi.columns_of_rank(sc.width, rank, world)
         bufs = dict(
             rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),

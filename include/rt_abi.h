@@ -97,6 +97,7 @@ typedef struct rt_params {
     int32_t  lambertian_samples;  /* Lambertian SampleCount; 0 = 4 (Surface.fs:63); 1..4      */
     int32_t  x_begin, x_end, x_step;
     int32_t  waves_per_cu;        /* tuning: cap on resident persistent waves per CU; 0 = all that fit */
+    int32_t  pool_blocks;         /* tuning: 64-record pool blocks kept in LDS per wave (rest spills to HBM); 0 = auto */
 } rt_params;
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident SoA scene + workspace          */
@@ -145,7 +146,7 @@ const char* rt_last_error(void);
 
 /* ABI version: bumped whenever a struct layout or signature changes.                         */
 int  rt_abi_version(void);
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ RT_E_UNSUPPORTED = -5
 KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 
 
 class rt_surface(C.Structure):
@@ -58,6 +58,7 @@ class rt_params(C.Structure):
         ("x_end", C.c_int32),
         ("x_step", C.c_int32),
         ("waves_per_cu", C.c_int32),
+        ("pool_blocks", C.c_int32),
     ]
 
 

@@ -99,6 +99,8 @@ struct rt_scene {
     unsigned long long* d_counter = nullptr;   // work counter of the persistent waves
     unsigned long long* d_accum = nullptr;     // per-pixel 32.32 radiance sums (grown on demand)
     size_t accum_bytes = 0;
+    uint32_t* d_spill = nullptr;               // pool blocks spilled by the persistent waves (grown on demand)
+    size_t spill_bytes = 0;
     int num_cus = 0;
     int occ_smem[2] = { -1, -1 };              // LDS size the cached occupancy below was queried for
     int occ_per_cu[2] = { 0, 0 };
@@ -142,6 +144,7 @@ int check_params(const rt_camera* cam, const rt_params* p)
     if (p->x_step <= 0 || p->x_begin < 0 || p->x_end > p->width || p->x_begin > p->x_end)
         return fail(RT_E_INVALID, "bad column range x_begin/x_end/x_step");
     if (p->waves_per_cu < 0 || p->waves_per_cu > 32) return fail(RT_E_INVALID, "waves_per_cu must be in 0..32");
+    if (p->pool_blocks < 0 || p->pool_blocks > 32) return fail(RT_E_INVALID, "pool_blocks must be in 0..32");
     return RT_OK;
 }
 
@@ -154,8 +157,17 @@ int ensure_accum(rt_scene* sc, size_t bytes)
     return RT_OK;
 }
 
+int ensure_spill(rt_scene* sc, size_t bytes)
+{
+    if (sc->spill_bytes >= bytes) return RT_OK;
+    if (sc->d_spill) { HIP_TRY(hipFree(sc->d_spill)); sc->d_spill = nullptr; sc->spill_bytes = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_spill), bytes));
+    sc->spill_bytes = bytes;
+    return RT_OK;
+}
+
 template <bool NODE64>
-int launch_trace(rt_scene* sc, const ColdArgs& c, const RenderArgs& a, const ShadeRec* shade, int waves_per_cu,
+int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec* shade, int waves_per_cu,
                  size_t smem, hipStream_t stream)
 {
     const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64>);
@@ -175,6 +187,9 @@ int launch_trace(rt_scene* sc, const ColdArgs& c, const RenderArgs& a, const Sha
     const unsigned long long chunks = (c.total + 63) / 64;
     unsigned long long grid = (unsigned long long)per_cu * (unsigned long long)sc->num_cus;
     if (grid > chunks) grid = chunks;
+    int rc = ensure_spill(sc, (size_t)grid * a.max_spill * (NODE64 ? 12 : 11) * 64 * sizeof(uint32_t));
+    if (rc) return rc;
+    c.spill = sc->d_spill;
     hipLaunchKernelGGL((trace_kernel<NODE64>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, shade);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -282,6 +297,7 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_status) (void)hipFree(sc->d_status);
     if (sc->d_counter) (void)hipFree(sc->d_counter);
     if (sc->d_accum) (void)hipFree(sc->d_accum);
+    if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
     delete sc;
 }
@@ -331,8 +347,12 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
-    // (DESIGN.md "Pool bound")
-    a.cap = 64 * (p->max_trace_depth + 1 + a.bg_nonzero);
+    // (DESIGN.md "Pool bound"); the top pool_blocks blocks live in LDS, the rest spills to HBM
+    const int levels = p->max_trace_depth + 1 + a.bg_nonzero;
+    a.nblk = p->pool_blocks > 0 ? p->pool_blocks : 2;   // measured: 2 blocks (19 waves/CU) beats 3, 4, 6
+    if (a.nblk > levels) a.nblk = levels;
+    if (a.nblk < 2 && levels >= 2) a.nblk = 2;
+    a.max_spill = levels;
 
     // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
     const float* M = cam->cam_to_world;
@@ -345,7 +365,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     c.tan_half = tanf(cam->fov / 2.0f);
 
     const bool node64 = p->max_trace_depth > 13;
-    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)(node64 ? 12 : 11) * a.cap);
+    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)(node64 ? 12 : 11) * 64 * a.nblk);
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));

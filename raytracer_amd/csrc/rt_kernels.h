@@ -47,11 +47,14 @@ struct ColdArgs {
     unsigned long long* ids;        // [ncols*H] or null
     unsigned long long* stats;      // RT_STATS_WORDS u64, or null
     int* status;                    // overflow flag
+    uint32_t* spill;                // [waves][max_spill][NF*64] pool blocks spilled to HBM
 };
 
 // Hot constants: live in SGPRs for the whole kernel.
 struct RenderArgs {
-    int nsurf, spp, max_depth, bg_nonzero, cap;
+    int nsurf, spp, max_depth, bg_nonzero;
+    int nblk;                       // 64-record blocks of the pool kept in LDS
+    int max_spill;                  // blocks one wave may spill to HBM (= record levels)
     uint32_t seed_lo, seed_hi;
 };
 
@@ -104,7 +107,6 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
-    const int cap = a.cap;
     constexpr int NF = NODE64 ? 12 : 11;
     unsigned long long* sl_acc = reinterpret_cast<unsigned long long*>(smem + kLdsAcc);
     unsigned long long* sl_ps = reinterpret_cast<unsigned long long*>(smem + kLdsPs);
@@ -115,7 +117,17 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     // Record r lives in block r/64: field f of record r is the dword pool[(r/64)*NF*64 + f*64 + r%64], so a
     // field is an immediate offset (f*256 bytes) from the record's base address and lanes reading
     // consecutive records hit consecutive banks.
-    auto rec_base = [&](int r) -> uint32_t* { return pool + ((r >> 6) * (NF * 64) + (r & 63)); };
+    // The LDS holds the top nblk blocks of the pool as a ring (base_blk = physical block of logical block 0);
+    // when a push would not fit, the bottom block (the shallowest 64 records, needed last) is spilled to
+    // HBM and reloaded once everything above it has been consumed.  Typical depth is ~100 records, the
+    // proven bound 64 per level: the ring keeps LDS per wave small (more waves per CU) without giving up
+    // the bound.
+    int base_blk = 0, nspill = 0;
+    auto rec_base = [&](int r) -> uint32_t* {
+        int b = (r >> 6) + base_blk;
+        b = (b >= a.nblk) ? b - a.nblk : b;
+        return pool + (b * (NF * 64) + (r & 63));
+    };
     enum { F_PX = 0, F_PY = 64, F_PZ = 128, F_DX = 192, F_DY = 256, F_DZ = 320, F_BX = 384, F_BY = 448, F_BZ = 512,
            F_META = 576, F_NODE = 640, F_NODEHI = 704 };
 
@@ -131,8 +143,19 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     bool overflow = false;
     uint32_t n_iter = 0, n_prim_iter = 0;       // diagnostics (wave-uniform)
     int spins = 0;
+    int maxtop = 0;
 
     while (true) {
+        if (top == 0 && nspill > 0) {
+            // ---- the LDS part of the pool is consumed: bring back the most recently spilled block
+            nspill--;
+            const uint32_t* src = cold_args()->spill + ((size_t)blockIdx.x * a.max_spill + nspill) * (NF * 64) + lane;
+            uint32_t* dst = pool + base_blk * (NF * 64) + lane;
+#pragma unroll
+            for (int f = 0; f < NF; f++) dst[f * 64] = src[f * 64];
+            top = 64;
+            __syncthreads();
+        }
         // ---- take the top records whose children fit in 64 lanes (prefix sum over ballots)
         int nchild = 0;
         uint32_t mp = 0u;
@@ -155,7 +178,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         }
         // ---- the pool is drained: start new pixel-samples in the free lanes
         int nprim = 0;
-        if (top == 0 && nchild < 64 && !exhausted) {
+        if (top == 0 && nspill == 0 && nchild < 64 && !exhausted) {
             // pull exactly as many pixel-samples as there are free lanes (and free slots): one returning
             // atomic per refill keeps the hand-out fine-grained, so no wave is left holding a queue of
             // expensive pixels while the others have finished
@@ -171,6 +194,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             }
         }
         if (nchild + nprim == 0) {
+            if (nspill > 0) continue;           // (cannot happen: a reloaded block always yields children)
             if (exhausted) break;               // nothing in the pool, nothing left to start
             if (++spins > 4) { overflow = true; break; }   // cannot happen (all slots are free here): never spin
             continue;
@@ -368,8 +392,20 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         // ---- compaction: hits on scattering surfaces become records, deepest on top
         const unsigned long long pm = __ballot(push);
         const int npush = __popcll(pm);
-        if (top + npush > cap) { overflow = true; }
-        else {
+        if (top + npush > a.nblk * 64) {
+            // ---- no room: spill the bottom block of the ring (top >= 64 here, so it is full)
+            if (nspill < a.max_spill) {
+                uint32_t* dst = cold_args()->spill + ((size_t)blockIdx.x * a.max_spill + nspill) * (NF * 64) + lane;
+                const uint32_t* src = pool + base_blk * (NF * 64) + lane;
+#pragma unroll
+                for (int f = 0; f < NF; f++) dst[f * 64] = src[f * 64];
+                nspill++;
+                base_blk = (base_blk + 1 == a.nblk) ? 0 : base_blk + 1;
+                top -= 64;
+                __syncthreads();
+            } else overflow = true;             // beyond 64 records per level: a bug
+        }
+        if (top + npush <= a.nblk * 64) {
             if (push) {
                 const int pos = top + (npush - 1 - mbcnt64(pm));
                 uint32_t* wb = rec_base(pos);
@@ -382,6 +418,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
                 atomicAdd(&sl_pend[slot], 1u);
             }
             top += npush;
+            maxtop = max(maxtop, top + 64 * nspill);
         }
         // ---- retire: every popped record and every primary gives back one pending unit of its slot
         //      (after this iteration's pushes, so the count reaches 0 only when the whole tree is done)
@@ -419,7 +456,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             atomicAdd(stats + 0, r);
             atomicMax(reinterpret_cast<unsigned int*>(stats + 1), __float_as_uint(m));
             atomicAdd(stats + 2, (unsigned long long)n_iter);
-            atomicAdd(stats + 3, (unsigned long long)n_prim_iter);
+            atomicMax(stats + 3, (unsigned long long)maxtop); atomicAdd(stats + 7, (unsigned long long)maxtop << 32);
             atomicMax(stats + 4, (unsigned long long)n_iter);
             const unsigned long long dt = __builtin_readcyclecounter() - t_start;
             atomicMax(stats + 5, dt);

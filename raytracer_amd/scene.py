@@ -17,14 +17,14 @@ from . import abi, host
 class Scene:
     def __init__(self, surfaces=None, width=800, height=640, samplesPerPixel=1, maxTraceDepth=5,
                  backgroundColor=(0.0, 0.0, 0.0), cameraOriginWS=(-3.0, 6.0, 15.0), lookAt=(-1.0, 1.0, -10.0),
-                 fov=None, seed=1, jitter=1, lambertian_samples=0, device=0, waves_per_cu=0):
+                 fov=None, seed=1, jitter=1, lambertian_samples=0, device=0, waves_per_cu=0, pool_blocks=0):
         self.surfaces = list(host.SceneDefinitions.scene_spheres if surfaces is None else surfaces)   # Scene.fs:33
         self.width, self.height = int(width), int(height)                                             # Scene.fs:18-19
         self.samplesPerPixel, self.maxTraceDepth = int(samplesPerPixel), int(maxTraceDepth)           # Scene.fs:20,31
         self.backgroundColor = tuple(backgroundColor)                                                 # Scene.fs:32
         self.camera = host.make_camera(cameraOriginWS, lookAt, (0.0, 1.0, 0.0), fov)                  # Scene.fs:36-43
         self.seed, self.jitter, self.lambertian_samples = int(seed), int(jitter), int(lambertian_samples)
-        self.device, self.waves_per_cu = int(device), int(waves_per_cu)
+        self.device, self.waves_per_cu, self.pool_blocks = int(device), int(waves_per_cu), int(pool_blocks)
         self.frameBuffer = np.zeros((self.width, self.height, 4), dtype=np.float32)                  # Scene.fs:28
         self.depthBuffer = np.full((self.width, self.height), np.finfo(np.float32).max, dtype=np.float32)  # Scene.fs:29
         self.objectIds = np.zeros((self.width, self.height), dtype=np.uint64)
@@ -37,7 +37,7 @@ class Scene:
     def params(self, x_begin=0, x_end=None, x_step=1):
         return host.make_params(self.width, self.height, self.samplesPerPixel, self.maxTraceDepth,
                                 self.backgroundColor, self.jitter, self.seed, self.lambertian_samples,
-                                x_begin, x_end, x_step, self.waves_per_cu)
+                                x_begin, x_end, x_step, self.waves_per_cu, self.pool_blocks)
 
     def upload(self):
         """Flatten the surfaces and upload them once to HBM (rt_scene_create)."""

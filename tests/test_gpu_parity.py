@@ -58,6 +58,12 @@ def test_trace_depths(depth):
     _compare(Scene(width=96, height=64, samplesPerPixel=1, maxTraceDepth=depth, jitter=1, seed=3))
 
 
+@pytest.mark.parametrize("blocks", [2, 4, 6])
+def test_pool_blocks_spill(blocks):
+    """Small LDS pools force the spill-to-HBM path of the record pool; results must not change."""
+    _compare(Scene(width=160, height=120, samplesPerPixel=2, maxTraceDepth=5, jitter=1, seed=5, pool_blocks=blocks))
+
+
 @pytest.mark.parametrize("waves", [1, 3])
 def test_waves_per_cu(waves):
     _compare(Scene(width=100, height=75, samplesPerPixel=2, maxTraceDepth=4, jitter=1, seed=5, waves_per_cu=waves))
