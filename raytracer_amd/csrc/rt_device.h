@@ -193,42 +193,53 @@ RT_DEV void frame_around(f3 n, f3& nt, f3& nb)
 }
 
 // ---- closest hit --------------------------------------------------------------------------
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// One GeomRec into 20 SGPRs, asynchronously (the compiler's own scalar loads are placed right before
+// their first use, which exposes the scalar-cache latency once per surface; issued by hand, the load of
+// surface i+1 overlaps the arithmetic of surface i).  geom_wait() must precede the first use.
+RT_DEV void geom_load(const GeomRec* rec, v16f& lo, v4f& hi)
+{
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40" : "=&s"(lo), "=&s"(hi) : "s"(rec) : "memory");
+}
+RT_DEV void geom_wait(v16f& lo, v4f& hi) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi)); }
+
 // findClosestIntersection (Surface.fs:49-58): linear scan in array order, strict '<' so the first
 // surface wins ties; each candidate passes Hitable.Intersect + IntersectionAcceptable(.., 1.0, P).
-// `geom` is indexed with a wave-uniform i: the compiler turns the reads into s_load_dwordx4/x8
-// and the operands stay in SGPRs.
+// The loop index is wave-uniform: each surface's record sits in SGPRs and costs no vector register.
+// Conditions are combined with '&' so that no short-circuit branch is generated.
 RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D, int& idx_out, float& t_out)
 {
     int idx = -1;
     float tmin = kFltMax;
-    // The record of surface i+1 is requested (five s_load_dwordx4) before surface i is evaluated, so
-    // the scalar-cache latency overlaps the arithmetic; conditions are combined with '&' so that no
-    // short-circuit branch (and no load behind it) is generated.
-    const float4* __restrict__ gp = reinterpret_cast<const float4*>(geom);
-    float4 ra, rb, rc, rd, re;
-    if (nsurf > 0) { ra = gp[0]; rb = gp[1]; rc = gp[2]; rd = gp[3]; re = gp[4]; }
+    v16f r; v4f rh;
+    if (nsurf > 0) { geom_load(geom, r, rh); geom_wait(r, rh); }
     for (int i = 0; i < nsurf; i++) {
-        const int j = (i + 1 < nsurf) ? i + 1 : i;
-        const float4 na = gp[5 * j + 0], nb = gp[5 * j + 1], nc = gp[5 * j + 2], nd = gp[5 * j + 3], ne = gp[5 * j + 4];
-        const int type = __float_as_int(re.y);
+        v16f nr; v4f nrh;
+        geom_load(geom + ((i + 1 < nsurf) ? i + 1 : i), nr, nrh);
+        const int type = __float_as_int(rh[1]);
         float t; bool ok;
         if (type == kGeomSphere) {
-            // Sphere.fs:18-36,42-43
-            const f3 ctr = O - F3(ra.x, ra.y, ra.z);
-            const float B = 2.0f * dot(ctr, D);
-            const float C = dot(ctr, ctr) - ra.w;
-            const float disc = B * B - 4.0f * C;
-            const bool has = !(disc < 0.0f) & !rounds_to(disc, 1e3f, 0.0f);
-            const float sq = sqrt_rn(disc);
-            const float i1 = (-B + sq) / 2.0f, i2 = (-B - sq) / 2.0f;
+            // Sphere.fs:18-36,42-43, with B = 2b and disc = 4d factored out: b = dot(ctr, D),
+            // d = b*b - C.  Scaling by 2 and 4 is exact in binary floating point and commutes with
+            // rounding, so (-B +- sqrt(disc))/2 == -b +- sqrt(d) bit for bit, disc < 0 <=> d < 0, and
+            // Round(disc,3) = 0 <=> rint(4*fl(1000 d)) = 0 <=> |fl(1000 d)| <= 0.125.
+            const f3 ctr = O - F3(r[0], r[1], r[2]);
+            const float b = dot(ctr, D);
+            const float C = dot(ctr, ctr) - r[3];
+            const float d = b * b - C;
+            const bool has = !(d < 0.0f) & !(fabsf(d * 1e3f) <= 0.125f);
+            const float sq = sqrt_rn(d);
+            const float i1 = -b + sq, i2 = -b - sq;
             const float tboth = (i1 < i2) ? i1 : i2;
             const float tone = (i1 < 0.0f) ? i2 : i1;
             t = ((i1 >= kTMin) & (i2 >= kTMin)) ? tboth : tone;
             ok = has & (t > kTMin);
         } else {
             // Plane.fs:36-40,45-49
-            const f3 N = F3(ra.x, ra.y, ra.z);
-            const float num = -ra.w - dot(N, O);
+            const f3 N = F3(r[0], r[1], r[2]);
+            const float num = -r[3] - dot(N, O);
             const float den = dot(N, D);
             const bool has = !(fabsf(den) < kTMin);
             t = div_rn(num, den);
@@ -236,18 +247,19 @@ RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D,
             if (type == kGeomPlaneRect) {
                 // Plane.fs:19-34 with the per-plane constants hoisted
                 const f3 P = O + D * t;                                    // Core.fs:59
-                const f3 kern = F3(rd.x, rd.y, rd.z);
+                const f3 kern = F3(r[12], r[13], r[14]);
                 const f3 v = P - kern;
-                const float nx = kern.x + (((v.x * rb.x + v.y * rb.y) + v.z * rb.z) + 0.0f);
-                const float ny = kern.y + (((v.x * rc.x + v.y * rc.y) + v.z * rc.z) + 0.0f);
+                const float nx = kern.x + (((v.x * r[4] + v.y * r[5]) + v.z * r[6]) + 0.0f);
+                const float ny = kern.y + (((v.x * r[8] + v.y * r[9]) + v.z * r[10]) + 0.0f);
                 // xmin <= nx <= xmax  <=>  med3(nx, xmin, xmax) == nx  (bounds ordered: w, h >= 0)
-                ok = ok & (__builtin_amdgcn_fmed3f(nx, rc.w, rb.w) == nx) & (__builtin_amdgcn_fmed3f(ny, re.x, rd.w) == ny);
+                ok = ok & (__builtin_amdgcn_fmed3f(nx, r[11], r[7]) == nx) & (__builtin_amdgcn_fmed3f(ny, rh[0], r[15]) == ny);
             }
         }
         const bool better = ok & (t < tmin);
         tmin = better ? t : tmin;
         idx = better ? i : idx;
-        ra = na; rb = nb; rc = nc; rd = nd; re = ne;
+        geom_wait(nr, nrh);
+        r = nr; rh = nrh;
     }
     idx_out = idx; t_out = tmin;
 }

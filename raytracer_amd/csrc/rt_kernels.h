@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             const int kind = (meta >> 16) & 3, gty = (meta >> 18) & 3;
             const uint32_t surf = meta >> 20;
             clevel = level + 1;
-            cnode = 4ull * node + (uint64_t)child + 1ull;
+            cnode = NODE64 ? 4ull * node + (uint64_t)child + 1ull : (uint64_t)(4u * (uint32_t)node + (uint32_t)child + 1u);
             const uint64_t ps = sl_ps[slot];                      // the RNG counter
             owner = (child == 0);
 
@@ -278,64 +278,71 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             const float4 nc = *reinterpret_cast<const float4*>(&sr->nc[0]);
             const f3 albedo = F3(al.x, al.y, al.z);
 
+            // The three Scatter/Fresnel routines are interleaved so that their common steps (one
+            // Vector3.Normalize each) run once for all lanes with per-lane operands: every lane still
+            // performs exactly the operations of its own kind, in the reference's order.
             // Hitable.NormalForSurfacePoint: Sphere.fs:37-38, Plane.fs:50-51
-            f3 normal = F3(nc.x, nc.y, nc.z);
-            if (gty == kGeomSphere) normal = normalize(O - normal);
+            f3 n0 = F3(nc.x, nc.y, nc.z);
+            if (gty == kGeomSphere) n0 = normalize(O - n0);
+            // Metal (Surface.fs:94) and Dielectric (Surface.fs:136) renormalise it, Lambertian does not
+            f3 n1 = n0;
+            if (kind != kKindLambert) n1 = normalize(n0);
 
             alive = true;
-            f3 shd;                 // shading_i; folded into beta below
-            float inv_n;
+            f3 w = n1;              // the vector whose Normalize gives the scattered / modified / refracted direction
+            float cos_l = 0.0f;     // Lambertian: cos(theta) = sample.Y (Surface.fs:73)
+            if (kind != kKindDielectric) {
+                // Lambertian.Scatter (Surface.fs:66-83) / Metal.Scatter (Surface.fs:93-109): hemisphere
+                // sample in the frame around the normal
+                const f3 rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode);
+                f3 nt, nb;
+                frame_around(n1, nt, nb);
+                // Vector4.Transform(rn, ChangeOfBase nt n nb): rows nt, n, nb; M4x = 0
+                const f3 ns = F3(((rn.x * nt.x + rn.y * n1.x) + rn.z * nb.x) + 0.0f,
+                                 ((rn.x * nt.y + rn.y * n1.y) + rn.z * nb.y) + 0.0f,
+                                 ((rn.x * nt.z + rn.y * n1.z) + rn.z * nb.z) + 0.0f);
+                const float fuzz = al.w;
+                w = (kind == kKindLambert) ? ns : n1 * (1.0f - fuzz) + ns * fuzz;
+                cos_l = rn.y;
+            }
+            float F = 1.0f; bool single = true;
             if (kind == kKindDielectric) {
                 // Surface.fs:124-153 CalcFresnel + :168-181 GenerateSamples
-                normal = normalize(normal);
-                const f3 refl = normalize(reflect(Din, normal));
                 float eta_i, eta_t; f3 fn;
-                if (dot(Din, normal) > 0.0f) { eta_i = al.w; eta_t = 1.0f; fn = neg(normal); }
-                else                         { eta_i = 1.0f; eta_t = al.w; fn = normal; }
+                if (dot(Din, n1) > 0.0f) { eta_i = al.w; eta_t = 1.0f; fn = neg(n1); }
+                else                     { eta_i = 1.0f; eta_t = al.w; fn = n1; }
                 const float cos_i = dot(Din, neg(fn));
                 const float eta = div_rn(eta_i, eta_t);
                 const float disc = 1.0f - (eta * eta) * (1.0f - (cos_i * cos_i));
-                const bool refracted = disc > 0.0f;
-                float F = 1.0f;
-                if (refracted) {
+                if (disc > 0.0f) {
                     const float q = div_rn(eta_t - eta_i, eta_t + eta_i);
                     const float R0 = q * q;
                     F = R0 + (1.0f - R0) * pow5(1.0f - cos_i);
                 }
-                const bool single = rounds_to(F, 1e3f, 1e3f);      // Round(F,3) = 1
-                if (child == 0) {
-                    Dn = make_ray_dir(refl);
-                    shd = albedo * F;                      // (2*albedo*F)/2 == albedo*F exactly
-                } else {
-                    alive = !single;
-                    const f3 q = (Din + fn * cos_i) * eta - fn * sqrt_rn(disc);
-                    Dn = make_ray_dir(normalize(q));
-                    shd = albedo * (1.0f - F);
-                }
-                inv_n = 1.0f;
-            } else {
-                // Lambertian.Scatter (Surface.fs:66-83) / Metal.Scatter (Surface.fs:93-109)
-                if (kind == kKindMetal) normal = normalize(normal);
-                const f3 rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode);
-                f3 nt, nb;
-                frame_around(normal, nt, nb);
-                // Vector4.Transform(rn, ChangeOfBase nt n nb): rows nt, n, nb; M4x = 0
-                const f3 ns = F3(((rn.x * nt.x + rn.y * normal.x) + rn.z * nb.x) + 0.0f,
-                                 ((rn.x * nt.y + rn.y * normal.y) + rn.z * nb.y) + 0.0f,
-                                 ((rn.x * nt.z + rn.y * normal.z) + rn.z * nb.z) + 0.0f);
-                if (kind == kKindLambert) {
-                    Dn = make_ray_dir(normalize(ns));
-                    const float pdf = 1.0f / (2.0f * 3.14159265358979323846f);
-                    const f3 brdf = divs(albedo, 3.14159265358979323846f);
-                    shd = brdf * div_rn(rn.y, pdf);
-                } else {
-                    const float fuzz = al.w;
-                    const f3 mod = normalize(normal * (1.0f - fuzz) + ns * fuzz);
-                    Dn = make_ray_dir(normalize(reflect(Din, mod)));
-                    shd = albedo * (1.0f / 1.0f);
-                }
-                inv_n = div_rn(1.0f, (float)n);
+                single = rounds_to(F, 1e3f, 1e3f);                  // Round(F,3) = 1: reflection only
+                w = (Din + fn * cos_i) * eta - fn * sqrt_rn(disc);  // refraction direction before Normalize
+                if (child == 1) alive = !single;
             }
+            const f3 u = normalize(w);
+            // Metal reflects about the fuzzed normal u, Dielectric about n1; Lambertian keeps u
+            f3 r = u;
+            if (kind != kKindLambert) r = normalize(reflect(Din, (kind == kKindMetal) ? u : n1));
+            const bool use_u = (kind == kKindLambert) | ((kind == kKindDielectric) & (child == 1));
+            Dn = make_ray_dir(use_u ? u : r);
+
+            f3 shd;                 // shading_i; folded into beta below
+            float inv_n = 1.0f;
+            if (kind == kKindLambert) {
+                const float pdf = 1.0f / (2.0f * 3.14159265358979323846f);
+                const f3 brdf = albedo * (1.0f / 3.14159265358979323846f);   // Vector3 / float = v * (1/f)
+                shd = brdf * div_rn(cos_l, pdf);
+            } else if (kind == kKindMetal) {
+                shd = albedo * (1.0f / 1.0f);
+            } else {
+                shd = albedo * ((child == 0) ? F : (1.0f - F));   // (2*albedo*F)/2 == albedo*F exactly
+            }
+            if (kind != kKindDielectric)
+                inv_n = (n == 1) ? 1.0f : (n == 2) ? 0.5f : (n == 3) ? (1.0f / 3.0f) : 0.25f;   // 1/n, correctly rounded
             beta = (pbeta * shd) * inv_n;
 
             if (alive && clevel > a.max_depth + 1) {
@@ -428,9 +435,11 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             // the pixel-sample is complete: add it to its pixel (order-independent integer adds)
             const ColdArgs* ca = cold_args();
             unsigned long long* dst = ca->accum + (size_t)sl_pix[slot] * 3;
+#ifndef RT_EXPERIMENT_NOFLUSH
             atomicAdd(dst + 0, sl_acc[slot * 3 + 0]);
             atomicAdd(dst + 1, sl_acc[slot * 3 + 1]);
             atomicAdd(dst + 2, sl_acc[slot * 3 + 2]);
+#endif
         }
         unsigned long long dm = __ballot(done);
         while (dm) {
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             atomicAdd(stats + 0, r);
             atomicMax(reinterpret_cast<unsigned int*>(stats + 1), __float_as_uint(m));
             atomicAdd(stats + 2, (unsigned long long)n_iter);
-            atomicMax(stats + 3, (unsigned long long)maxtop); atomicAdd(stats + 7, (unsigned long long)maxtop << 32);
+            atomicAdd(stats + 3, (unsigned long long)n_prim_iter);
             atomicMax(stats + 4, (unsigned long long)n_iter);
             const unsigned long long dt = __builtin_readcyclecounter() - t_start;
             atomicMax(stats + 5, dt);
