@@ -3,7 +3,7 @@
 
   oracle_c1_64x48.npz      oracle render: scene_spheres, 64x48, 1 spp, maxTraceDepth 5, pinhole
   oracle_c2_48x36.npz      oracle render: scene_spheres, 48x36, 4 spp, maxTraceDepth 4, jitter, seed 7
-  oracle_ref_40x30_hi.npz  oracle render: 40x30, 32768 spp, maxTraceDepth 4, seed 1001 (the high-spp
+  oracle_ref_40x30_hi.npz  oracle render: 40x30, 32768 spp, maxTraceDepth 4, pinhole, seed 1001 (the high-spp
                            reference of the PSNR check; ~1.5 minutes on 8 cores)
   display_100x80.npy       the reference's own render display.jpg (800x640) box-filtered 8x8 to 100x80 RGB
                            u8 -- DATA from /root/reference (a soft visual fixture)
@@ -36,7 +36,7 @@ def main(which):
     if "c2" in which:
         save("oracle_c2_48x36.npz", O.render(sc, cam, host.make_params(48, 36, 4, 4, jitter=1, seed=7)))
     if "hi" in which:
-        r = O.render(sc, cam, host.make_params(40, 30, 32768, 4, jitter=1, seed=1001))
+        r = O.render(sc, cam, host.make_params(40, 30, 32768, 4, jitter=0, seed=1001))
         np.savez_compressed(os.path.join(HERE, "oracle_ref_40x30_hi.npz"), rgba=r["rgba"], rays=np.uint64(r["rays"]))
     if "display" in which:
         from PIL import Image

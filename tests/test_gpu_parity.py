@@ -162,10 +162,15 @@ def test_gpu_matches_committed_golden(name, kw):
 
 def test_psnr_against_high_spp_reference():
     """north_star: stochastic multi-sample renders reach PSNR >= 40 dB against a high-spp reference.
-    Reference = the oracle at 32768 spp (seed 1001, committed); GPU = 65536 spp with another seed, so
-    the two share no random numbers and the check is statistical, not a replay."""
+    Reference = the oracle at 32768 spp (seed 1001, committed); GPU = 4096 spp with another seed, so the
+    two share no random numbers and the check is statistical, not a replay (measured: 1024 spp 44 dB,
+    16384 spp 54.5 dB).  Both use the pinhole primary ray: the reference draws ONE sub-pixel offset per
+    pixel and seed (Scene.fs:98-104, Camera.fs:8-17), not one per sample, so renders with different seeds
+    look through slightly different primary rays and differ by up to 1.0 at silhouette pixels whatever the
+    sample count (measured 26-30 dB between seeds at 65536 spp with jitter on) -- that is the reference's
+    estimator, not noise that more samples remove."""
     want = np.load(os.path.join(G, "oracle_ref_40x30_hi.npz"))["rgba"]
-    s = Scene(width=40, height=30, samplesPerPixel=65536, maxTraceDepth=4, jitter=1, seed=77)
+    s = Scene(width=40, height=30, samplesPerPixel=4096, maxTraceDepth=4, jitter=0, seed=77)
     s.renderScene()
     mse = float(np.mean((s.frameBuffer[:, :, :3].astype(np.float64) - want[:, :, :3]) ** 2))
     psnr = 10 * np.log10(1.0 / mse)
