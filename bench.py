@@ -32,12 +32,27 @@ WORKLOADS = {
 
 # Algorithmic FP32 work per ray, counted from the reference's F# (SURVEY.md section 8(d)); sqrt and
 # divide count 1.  Closest hit on scene_spheres = 6 sphere tests (27) + 6 plane tests (13) + 5
-# rectangle tests (25) + 12 PointForRay (6) = 437 flops per ray.  Ray generation ("shade") adds
-# ~90 flops per Lambertian child, 60 per Metal child, 110 per Dielectric child, 30 per primary; the
-# kernel does not count children by kind, so the bench prices every ray at 437 + 60 (a lower bound
-# for this scene, where most children are Lambertian).
-FLOPS_PER_RAY = 437.0 + 60.0
-VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector
+# rectangle tests (25) + 12 PointForRay (6) = 437 flops per ray.  Generating the ray adds 90 flops per
+# Lambertian child, 60 per Metal child, 110 per Dielectric child and 30 per primary; the kernel counts
+# its rays by kind, so flops per launch = 437 rays + 90 nL + 60 nM + 110 nD + 30 nPrimary.
+FLOPS_SCAN, FLOPS_LAMB, FLOPS_METAL, FLOPS_DIEL, FLOPS_PRIMARY = 437.0, 90.0, 60.0, 110.0, 30.0
+VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (packed FMA); plain f32 ops issue at a quarter of it
+
+
+def launch_flops(d):
+    prim = d["rays"] - d["lamb"] - d["metal"] - d["diel"]
+    return (FLOPS_SCAN * d["rays"] + FLOPS_LAMB * d["lamb"] + FLOPS_METAL * d["metal"] + FLOPS_DIEL * d["diel"]
+            + FLOPS_PRIMARY * prim)
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch of rt::trace_kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md); None when that workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload)
+    except OSError:
+        return None
 
 
 def cpu_baseline():
@@ -122,8 +137,8 @@ def main():
             ev[1].record()
         st = bufs["stats"].cpu()        # syncs this stream: ray count + max depth bits of this rank
         rays = int(st[0].item())
-        diag["iters"], diag["prim_iters"] = int(st[2].item()), int(st[3].item())
-        diag["max_wave_iters"], diag["max_wave_clk"], diag["sum_wave_clk"], diag["waves"] = (int(st[i].item()) for i in (4, 5, 6, 7))
+        diag["rays"], diag["iters"] = rays, int(st[2].item())
+        diag["lamb"], diag["metal"], diag["diel"], diag["sum_wave_clk"], diag["waves"] = (int(st[i].item()) for i in (3, 4, 5, 6, 7))
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
         return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
 
@@ -154,8 +169,8 @@ def main():
     out = None
     if rank == 0:
         cfg = WORKLOADS[args.workload]
-        local_rays = rays_per_frame / world          # interleaved columns: equal shares to <1 %
-        achieved = local_rays * FLOPS_PER_RAY / (kern_ms * 1e-3) / 1e12
+        flops = launch_flops(diag)                     # rank 0's last launch (interleaved columns: equal shares to <1 %)
+        achieved = flops / (kern_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/s (primary+bounce)", "value": rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -164,12 +179,13 @@ def main():
                            args.workload, cfg["width"], cfg["height"], cfg["samplesPerPixel"], cfg["maxTraceDepth"], cfg["jitter"]),
                        "rays_per_frame": rays_per_frame, "partition": "interleaved columns, %d rank(s), RCCL gather to rank 0" % world},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "rt::render_kernel", "kernel_ms": kern_ms, "flops_per_ray": FLOPS_PER_RAY,
-                         "lane_fill": local_rays / max(1, diag.get("iters", 0) * 64), "iters": diag.get("iters"),
-                         "prim_iters": diag.get("prim_iters"), "waves": diag.get("waves"),
-                         "max_wave_iters": diag.get("max_wave_iters"), "max_wave_clk": diag.get("max_wave_clk"),
-                         "mean_wave_clk": diag.get("sum_wave_clk", 0) / max(1, diag.get("waves", 1))},
+                         "frac": achieved / VALU_PEAK_TFLOPS, "traffic": measured_traffic(args.workload) if world == 1 else None,
+                         "kernel": "rt::trace_kernel (+ memsets and rt::resolve_kernel, <1 % of the bracket)",
+                         "kernel_ms": kern_ms, "flops_per_launch": flops, "flops_per_ray": flops / max(1, diag["rays"]),
+                         "rays_by_kind": {"lambertian": diag["lamb"], "metal": diag["metal"], "dielectric": diag["diel"],
+                                          "primary": diag["rays"] - diag["lamb"] - diag["metal"] - diag["diel"]},
+                         "lane_fill": diag["rays"] / max(1, diag["iters"] * 64), "waves": diag["waves"],
+                         "mean_wave_clk": diag["sum_wave_clk"] / max(1, diag["waves"])},
         }
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}

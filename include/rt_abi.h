@@ -120,9 +120,9 @@ int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
 /* Same render, but asynchronous on `stream` (a hipStream_t; NULL = default stream) with DEVICE
  * output buffers, so a caller that owns device memory (torch, RCCL gather of the framebuffer)
  * never crosses PCIe.  d_stats points at RT_STATS_WORDS device u64: [0] ray count, [1] bit pattern
- * of max depth (f32) in the low word, [2] 64-ray loop iterations over all waves, [3] iterations
- * that started primary rays, [4] most iterations of one wave, [5] longest / [6] summed wave lifetime
- * in shader clocks, [7] waves ([2..7] are diagnostics); may be NULL.
+ * of max depth (f32) in the low word, [2] 64-ray loop iterations over all waves, [3] / [4] / [5] child
+ * rays scattered by Lambertian / Metal / Dielectric surfaces (ray count minus these = primary rays),
+ * [6] summed wave lifetimes in shader clocks, [7] waves; may be NULL.
  * No counterpart in the reference.                                                            */
 #define RT_STATS_WORDS 8
 int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,

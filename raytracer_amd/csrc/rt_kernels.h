@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     uint32_t nrays = 0;                         // closest-hit queries by this lane
     float maxd = 0.0f;
     bool overflow = false;
-    uint32_t n_iter = 0, n_prim_iter = 0;       // diagnostics (wave-uniform)
+    uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
+    uint32_t n_lamb = 0, n_metal = 0, n_diel = 0;   // child rays intersected, by the kind that scattered them
     int spins = 0;
-    int maxtop = 0;
 
     while (true) {
         if (top == 0 && nspill > 0) {
@@ -199,12 +199,13 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             if (++spins > 4) { overflow = true; break; }   // cannot happen (all slots are free here): never spin
             continue;
         }
-        n_iter++; n_prim_iter += (nprim > 0) ? 1u : 0u; spins = 0;
+        n_iter++; spins = 0;
         const bool is_child = lane < nchild;
         const bool is_prim = !is_child && lane < nchild + nprim;
 
         f3 O = F3(0, 0, 0), Dn = F3(0, 0, 0), beta = F3(1.0f, 1.0f, 1.0f);
         int slot = 0, clevel = 0; uint64_t cnode = 0;
+        int ckind = 0;                          // kind of the surface this lane's child ray leaves (0 = primary)
         bool alive = false;                     // this lane intersects a ray
         bool owner = false;                     // this lane retires one pending unit of its slot
         float dot_view = 1.0f; uint32_t prim_o = 0; bool prim_first = false;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             const int kind = (meta >> 16) & 3, gty = (meta >> 18) & 3;
             const uint32_t surf = meta >> 20;
             clevel = level + 1;
+            ckind = kind;
             cnode = NODE64 ? 4ull * node + (uint64_t)child + 1ull : (uint64_t)(4u * (uint32_t)node + (uint32_t)child + 1u);
             const uint64_t ps = sl_ps[slot];                      // the RNG counter
             owner = (child == 0);
@@ -355,6 +357,10 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             }
         }
 
+        n_lamb += (uint32_t)__popcll(__ballot(alive && ckind == kKindLambert));
+        n_metal += (uint32_t)__popcll(__ballot(alive && ckind == kKindMetal));
+        n_diel += (uint32_t)__popcll(__ballot(alive && ckind == kKindDielectric));
+
         // ============ findClosestIntersection + hit handling, all 64 lanes ============
         bool push = false;
         f3 P = F3(0, 0, 0);
@@ -425,7 +431,6 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
                 atomicAdd(&sl_pend[slot], 1u);
             }
             top += npush;
-            maxtop = max(maxtop, top + 64 * nspill);
         }
         // ---- retire: every popped record and every primary gives back one pending unit of its slot
         //      (after this iteration's pushes, so the count reaches 0 only when the whole tree is done)
@@ -465,11 +470,10 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             atomicAdd(stats + 0, r);
             atomicMax(reinterpret_cast<unsigned int*>(stats + 1), __float_as_uint(m));
             atomicAdd(stats + 2, (unsigned long long)n_iter);
-            atomicAdd(stats + 3, (unsigned long long)n_prim_iter);
-            atomicMax(stats + 4, (unsigned long long)n_iter);
-            const unsigned long long dt = __builtin_readcyclecounter() - t_start;
-            atomicMax(stats + 5, dt);
-            atomicAdd(stats + 6, dt);
+            atomicAdd(stats + 3, (unsigned long long)n_lamb);
+            atomicAdd(stats + 4, (unsigned long long)n_metal);
+            atomicAdd(stats + 5, (unsigned long long)n_diel);
+            atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
         }
     }
