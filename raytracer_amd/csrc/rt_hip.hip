@@ -322,7 +322,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     const ShadeRec* shade = nullptr;
     rc = shade_table(sc, lamb, &shade);
     if (rc) return rc;
-    rc = ensure_accum(sc, (size_t)npix * 3 * sizeof(unsigned long long));
+    rc = ensure_accum(sc, (size_t)npix * 4 * sizeof(unsigned long long));
     if (rc) return rc;
 
     RenderArgs a; memset(&a, 0, sizeof a);
@@ -370,7 +370,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(sc->d_accum, 0, (size_t)npix * 3 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_accum, 0, (size_t)npix * 4 * sizeof(unsigned long long), stream));
     if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
     rc = node64 ? launch_trace<true>(sc, c, a, shade, p->waves_per_cu, smem, stream)
                 : launch_trace<false>(sc, c, a, shade, p->waves_per_cu, smem, stream);

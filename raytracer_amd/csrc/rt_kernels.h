@@ -42,7 +42,7 @@ struct ColdArgs {
     unsigned long long total;       // pixel-samples of this launch = ncols * H * spp
     unsigned int npix, scatter;     // hand-out order: pixel (i * scatter) mod npix, gcd(scatter, npix) = 1
     unsigned long long* counter;    // next pixel-sample to hand out
-    unsigned long long* accum;      // [ncols*H*3] per-pixel radiance sums, 32.32 fixed point
+    unsigned long long* accum;      // [ncols*H*4] per-pixel radiance sums (r,g,b,pad), 32.32 fixed point
     float* depth;                   // [ncols*H]
     unsigned long long* ids;        // [ncols*H] or null
     unsigned long long* stats;      // RT_STATS_WORDS u64, or null
@@ -436,21 +436,28 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         //      (after this iteration's pushes, so the count reaches 0 only when the whole tree is done)
         bool done = false;
         if (owner) done = atomicSub(&sl_pend[slot], 1u) == 1u;
-        if (done) {
-            // the pixel-sample is complete: add it to its pixel (order-independent integer adds)
-            const ColdArgs* ca = cold_args();
-            unsigned long long* dst = ca->accum + (size_t)sl_pix[slot] * 3;
-#ifndef RT_EXPERIMENT_NOFLUSH
-            atomicAdd(dst + 0, sl_acc[slot * 3 + 0]);
-            atomicAdd(dst + 1, sl_acc[slot * 3 + 1]);
-            atomicAdd(dst + 2, sl_acc[slot * 3 + 2]);
-#endif
-        }
         unsigned long long dm = __ballot(done);
-        while (dm) {
-            const int l = __builtin_ctzll(dm);
-            dm &= dm - 1;
-            freemask |= 1ull << __builtin_amdgcn_readlane(slot, l);
+        if (dm) {
+            // Finished pixel-samples are added to their pixels (order-independent integer adds).  The wave
+            // does it cooperatively: 4 lanes per finished slot, one per channel, so the three 8-byte adds
+            // of a pixel (32-byte aligned) travel as one atomic request instead of three wave-instructions
+            // with one lane each (measured: 33 B of HBM write per 8-byte add when issued separately).
+            const int ndone = __popcll(dm);
+            if (done) map[mbcnt64(dm)] = (uint32_t)slot;
+            __syncthreads();
+            const ColdArgs* ca = cold_args();
+            for (int base = 0; base < ndone; base += 16) {
+                const int k = base + (lane >> 2), ch = lane & 3;
+                if (k < ndone && ch < 3) {
+                    const int sl = (int)map[k];
+                    atomicAdd(ca->accum + (size_t)sl_pix[sl] * 4 + ch, sl_acc[sl * 3 + ch]);
+                }
+            }
+            while (dm) {
+                const int l = __builtin_ctzll(dm);
+                dm &= dm - 1;
+                freemask |= 1ull << __builtin_amdgcn_readlane(slot, l);
+            }
         }
         __syncthreads();
     }
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* 
     float c[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        const float sum = (float)((double)(long long)accum[o * 3 + ch] * 0x1p-32);   // one rounding
+        const float sum = (float)((double)(long long)accum[o * 4 + ch] * 0x1p-32);   // one rounding
         c[ch] = sum;
     }
     const f3 avg = divs(F3(c[0], c[1], c[2]), (float)spp);
