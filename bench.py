@@ -120,7 +120,7 @@ def main():
         bufs = dict(
             rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
             depth=torch.zeros((ncols, sc.height), dtype=torch.float32, device=dev),
-            stats=torch.zeros(8, dtype=torch.int64, device=dev),
+            stats=torch.zeros(12, dtype=torch.int64, device=dev),
         )
         g = multi.FrameGatherer(sc.width, sc.height, dev, rank, world)
         return sc, (xb, xe, xs), bufs, g

@@ -49,7 +49,11 @@ extern "C" {
 #define RT_GEOM_SPHERE     0   /* Geometry/Sphere.fs:8                                       */
 #define RT_GEOM_PLANE      1   /* Geometry/Plane.fs:12                                       */
 #define RT_GEOM_TRIANGLE   2   /* not in the reference (Geometry/AABB.fs is empty); obeys the
-                                  Hitable contract of Geometry/Core.fs:26-43                 */
+                                  Hitable contract of Geometry/Core.fs:26-43: Moeller-Trumbore
+                                  hit, accepted when t > TMin, constant normal
+                                  Normalize((v1-v0) x (v2-v0)), never flipped.  Scenes with
+                                  triangles or more than 64 surfaces are traced through a BVH
+                                  built at rt_scene_create; results equal the linear scan's.  */
 
 /* One `Surface` (Surface.fs:15) flattened: kind + material (Material.fs:9-18) + geometry.
  *   g[] for RT_GEOM_SPHERE  : center.xyz, radius                       (Sphere.fs:8)
@@ -122,9 +126,10 @@ int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
  * never crosses PCIe.  d_stats points at RT_STATS_WORDS device u64: [0] ray count, [1] bit pattern
  * of max depth (f32) in the low word, [2] 64-ray loop iterations over all waves, [3] / [4] / [5] child
  * rays scattered by Lambertian / Metal / Dielectric surfaces (ray count minus these = primary rays),
- * [6] summed wave lifetimes in shader clocks, [7] waves; may be NULL.
+ * [6] summed wave lifetimes in shader clocks, [7] waves, [8] BVH nodes visited, [9] BVH primitives
+ * tested (0 for linear-scan scenes), [10..11] reserved; may be NULL.
  * No counterpart in the reference.                                                            */
-#define RT_STATS_WORDS 8
+#define RT_STATS_WORDS 12
 int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);
@@ -146,7 +151,7 @@ const char* rt_last_error(void);
 
 /* ABI version: bumped whenever a struct layout or signature changes.                         */
 int  rt_abi_version(void);
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 #ifdef __cplusplus
 }

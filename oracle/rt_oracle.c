@@ -272,6 +272,9 @@ typedef struct {
     int has_center; v3 pcenter; float pw, ph;
     /* hoisted rectangle constants (identical values to the per-test recomputation) */
     m4 R; v3 kern; v3 newB;
+    /* triangle (NOT in the reference: Geometry/AABB.fs is empty and there is no triangle type; this is the
+       build's own Hitable, see triangle_intersect) */
+    v3 tv0, te1, te2, tn;
 } osurf;
 
 /* Sphere.fs:18-27 */
@@ -325,10 +328,28 @@ static void plane_intersect(const osurf *s, const ray_t *r, int *has, float *t)
     if (fabsf(den) < TMIN) { *has = 0; *t = 0.0f; }
     else { *has = 1; *t = num / den; }
 }
+/* Triangle as a Hitable (Geometry/Core.fs:26-43 contract): build-defined, no reference behaviour to
+ * match.  Moeller-Trumbore in f32, every operation in the order written:
+ *   p = D x e2; det = e1.p; |det| < 1e-12 -> no hit; inv = 1/det; tv = O - v0; u = (tv.p)*inv;
+ *   q = tv x e1; v = (D.q)*inv; hit iff u >= 0, v >= 0, u + v <= 1; t = (e2.q)*inv.
+ * Acceptable like a sphere: has && t > TMin (no TMax).  Normal = Normalize(e1 x e2), never flipped. */
+static void triangle_intersect(const osurf *s, const ray_t *r, int *has, float *t)
+{
+    v3 p = v3_cross(r->d, s->te2);
+    float det = v3_dot(s->te1, p);
+    float inv = 1.0f / det;
+    v3 tv = v3_sub(r->o, s->tv0);
+    float u = v3_dot(tv, p) * inv;
+    v3 q = v3_cross(tv, s->te1);
+    float v = v3_dot(r->d, q) * inv;
+    *t = v3_dot(s->te2, q) * inv;
+    *has = !(fabsf(det) < 1e-12f) && u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f;
+}
 /* Hitable.Intersect dispatch */
 static void geom_intersect(const osurf *s, const ray_t *r, int *has, float *t)
 {
     if (s->geom == RT_GEOM_SPHERE) sphere_intersect(s, r, has, t);
+    else if (s->geom == RT_GEOM_TRIANGLE) triangle_intersect(s, r, has, t);
     else plane_intersect(s, r, has, t);
 }
 /* Hitable.IntersectionAcceptable: Sphere.fs:42-43, Plane.fs:45-49 */
@@ -345,6 +366,7 @@ static int geom_acceptable(const osurf *s, int has, float t, float dot_view, v3 
 static v3 geom_normal(const osurf *s, v3 p)
 {
     if (s->geom == RT_GEOM_SPHERE) return v3_normalize(v3_sub(p, s->center));
+    if (s->geom == RT_GEOM_TRIANGLE) return s->tn;
     return s->pn;
 }
 
@@ -529,6 +551,11 @@ static void convert_surfaces(const rt_surface *in, int64_t n, int lamb_default, 
             s->has_center = a->g[4] != 0.0f;
             s->pcenter = V3(a->g[5], a->g[6], a->g[7]); s->pw = a->g[8]; s->ph = a->g[9];
             if (s->has_center) plane_rect_constants(s, &s->R, &s->kern, &s->newB);
+        } else if (a->geom == RT_GEOM_TRIANGLE) {
+            v3 v1 = V3(a->g[3], a->g[4], a->g[5]), v2 = V3(a->g[6], a->g[7], a->g[8]);
+            s->tv0 = V3(a->g[0], a->g[1], a->g[2]);
+            s->te1 = v3_sub(v1, s->tv0); s->te2 = v3_sub(v2, s->tv0);
+            s->tn = v3_normalize(v3_cross(s->te1, s->te2));
         }
     }
 }
@@ -541,7 +568,7 @@ static int check_args(const rt_surface *surf, int64_t n, const rt_camera *cam, c
     if (p->lambertian_samples < 0 || p->lambertian_samples > 4) return RT_E_INVALID;
     if (p->x_step <= 0 || p->x_begin < 0 || p->x_end > p->width || p->x_begin > p->x_end) return RT_E_INVALID;
     for (int64_t i = 0; i < n; i++) {
-        if (surf[i].kind < 0 || surf[i].kind > 3 || surf[i].geom < 0 || surf[i].geom > 1) return RT_E_INVALID;
+        if (surf[i].kind < 0 || surf[i].kind > 3 || surf[i].geom < 0 || surf[i].geom > 2) return RT_E_INVALID;
         if (surf[i].sample_count < 0 || surf[i].sample_count > 4) return RT_E_INVALID;
     }
     return RT_OK;
@@ -719,8 +746,9 @@ void rto_find_closest(const rt_surface *surfaces, int64_t n, int64_t nrays, cons
 {
     osurf *surf = (osurf *)malloc(sizeof(osurf) * (size_t)(n > 0 ? n : 1));
     convert_surfaces(surfaces, n, 4, surf);
-    octx c; memset(&c, 0, sizeof c); c.surf = surf; c.n = (int)n;
+#pragma omp parallel for schedule(dynamic, 16)
     for (int64_t i = 0; i < nrays; i++) {
+        octx c; memset(&c, 0, sizeof c); c.surf = surf; c.n = (int)n;
         ray_t r; r.o = V3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.d = V3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
         int b; float t;
         idx_out[i] = find_closest_intersection(&c, &r, &b, &t);

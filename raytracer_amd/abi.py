@@ -19,7 +19,7 @@ RT_E_UNSUPPORTED = -5
 KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
-RT_ABI_VERSION = 3
+RT_ABI_VERSION = 4
 
 
 class rt_surface(C.Structure):

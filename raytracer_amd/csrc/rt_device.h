@@ -19,7 +19,7 @@ constexpr float kFltMax = 3.402823466e+38f;
 
 // geometry types of the flattened scene (bounded and unbounded planes are split so the
 // closest-hit loop branches on a wave-uniform scalar)
-constexpr int kGeomSphere = 0, kGeomPlaneInf = 1, kGeomPlaneRect = 2;
+constexpr int kGeomSphere = 0, kGeomPlaneInf = 1, kGeomPlaneRect = 2, kGeomTriangle = 3;
 // surface kinds == RT_KIND_*
 constexpr int kKindNone = 0, kKindLambert = 1, kKindMetal = 2, kKindDielectric = 3;
 
@@ -34,7 +34,8 @@ struct alignas(16) GeomRec {
     float a[4], b[4], c[4], d[4];
     float ymin;
     int32_t type;
-    int32_t pad[2];
+    int32_t index;        // position in the caller's surface array (what the closest hit reports)
+    int32_t pad;
 };
 static_assert(sizeof(GeomRec) == 80, "GeomRec layout");
 
@@ -257,7 +258,7 @@ RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D,
         }
         const bool better = ok & (t < tmin);
         tmin = better ? t : tmin;
-        idx = better ? i : idx;
+        idx = better ? __float_as_int(rh[2]) : idx;
         geom_wait(nr, nrh);
         r = nr; rh = nrh;
     }

@@ -6,9 +6,11 @@
 // constants (Camera.fs:20-45, Scene.fs:100-102), launch geometry.  No CPU rendering path exists
 // in this library: without a HIP device every entry point returns RT_E_NO_DEVICE.
 #include "rt_kernels.h"
+#include "rt_bvh_build.h"
 
 #include "../../include/rt_abi.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -102,6 +104,10 @@ struct rt_scene {
     uint32_t* d_spill = nullptr;               // pool blocks spilled by the persistent waves (grown on demand)
     size_t spill_bytes = 0;
     int num_cus = 0;
+    int64_t nloose = 0;                        // entries of d_geom (all surfaces, or only the planes of a BVH scene)
+    bool use_bvh = false;
+    float4* d_nodes = nullptr; uint2* d_prims = nullptr; float4* d_pdata = nullptr;
+    int nnodes = 0, bvh_depth = 0;
     int occ_smem[2] = { -1, -1 };              // LDS size the cached occupancy below was queried for
     int occ_per_cu[2] = { 0, 0 };
     float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
@@ -166,11 +172,19 @@ int ensure_spill(rt_scene* sc, size_t bytes)
     return RT_OK;
 }
 
-template <bool NODE64>
+BvhRef bvh_ref(const rt_scene* sc)
+{
+    BvhRef b;
+    b.nodes = sc->d_nodes; b.prims = sc->d_prims; b.pdata = sc->d_pdata; b.nnodes = sc->nnodes;
+    return b;
+}
+
+template <bool NODE64, bool BVH>
 int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec* shade, int waves_per_cu,
                  size_t smem, hipStream_t stream)
 {
-    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64>);
+    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH>);
+    constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     // the attribute and the occupancy query cost host time: once per (kernel, LDS size) and scene
     int& cached_smem = sc->occ_smem[NODE64 ? 1 : 0];
     int& cached_per_cu = sc->occ_per_cu[NODE64 ? 1 : 0];
@@ -187,13 +201,17 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec*
     const unsigned long long chunks = (c.total + 63) / 64;
     unsigned long long grid = (unsigned long long)per_cu * (unsigned long long)sc->num_cus;
     if (grid > chunks) grid = chunks;
-    int rc = ensure_spill(sc, (size_t)grid * a.max_spill * (NODE64 ? 12 : 11) * 64 * sizeof(uint32_t));
+    int rc = ensure_spill(sc, (size_t)grid * a.max_spill * NF * 64 * sizeof(uint32_t));
     if (rc) return rc;
     c.spill = sc->d_spill;
-    hipLaunchKernelGGL((trace_kernel<NODE64>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, shade);
+    hipLaunchKernelGGL((trace_kernel<NODE64, BVH>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, shade,
+                       bvh_ref(sc));
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
+
+// A scene goes through the BVH when it has triangles or more spheres than a wave-uniform scan should test.
+constexpr int64_t kBvhThreshold = 64;
 
 }  // namespace
 
@@ -213,10 +231,20 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_E_NO_DEVICE, "no HIP device (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(RT_E_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
 
-    std::vector<GeomRec> geom((size_t)n);
+    std::vector<GeomRec> geom;
+    geom.reserve((size_t)std::min<int64_t>(n, 4096));
+    int64_t nprim = 0; bool any_tri = false;
+    for (int64_t i = 0; i < n; i++) {
+        if (surfaces[i].geom == RT_GEOM_SPHERE || surfaces[i].geom == RT_GEOM_TRIANGLE) nprim++;
+        if (surfaces[i].geom == RT_GEOM_TRIANGLE) any_tri = true;
+    }
+    const bool use_bvh = any_tri || n > kBvhThreshold;
+    std::vector<BuildPrim> bprims;
+    HostBvh hb;
+    if (use_bvh) bprims.reserve((size_t)nprim);
     rt_scene* sc = new (std::nothrow) rt_scene;
     if (!sc) return fail(RT_E_INVALID, "out of host memory");
-    sc->device = device; sc->n = n;
+    sc->device = device; sc->n = n; sc->use_bvh = use_bvh;
     sc->h_shade.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         const rt_surface& s = surfaces[i];
@@ -234,6 +262,33 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             g.a[0] = s.g[0]; g.a[1] = s.g[1]; g.a[2] = s.g[2];
             g.a[3] = s.g[3] * s.g[3];                                                   // Square radius, Sphere.fs:21
             h.nc[0] = s.g[0]; h.nc[1] = s.g[1]; h.nc[2] = s.g[2];
+            if (use_bvh) {
+                BuildPrim bp;
+                const float r = std::fabs(s.g[3]);
+                for (int k = 0; k < 3; k++) { bp.lo[k] = s.g[k] - r; bp.hi[k] = s.g[k] + r; bp.c[k] = s.g[k]; }
+                bp.ref = (uint32_t)hb.pdata.size(); bp.surf = (uint32_t)i;
+                hb.pdata.push_back(make_float4(g.a[0], g.a[1], g.a[2], g.a[3]));
+                bprims.push_back(bp);
+            }
+        } else if (s.geom == RT_GEOM_TRIANGLE) {
+            // the build's own Hitable (no reference counterpart): v0, e1 = v1 - v0, e2 = v2 - v0, constant
+            // normal Normalize(e1 x e2)
+            gtype = kGeomTriangle;
+            const H3 v0 = { s.g[0], s.g[1], s.g[2] };
+            const H3 e1 = { s.g[3] - v0.x, s.g[4] - v0.y, s.g[5] - v0.z }, e2 = { s.g[6] - v0.x, s.g[7] - v0.y, s.g[8] - v0.z };
+            const H3 tn = hnormalize(hcross(e1, e2));
+            h.nc[0] = tn.x; h.nc[1] = tn.y; h.nc[2] = tn.z;
+            BuildPrim bp;
+            for (int k = 0; k < 3; k++) {
+                const float a0 = s.g[k], a1 = s.g[3 + k], a2 = s.g[6 + k];
+                bp.lo[k] = std::min(a0, std::min(a1, a2)); bp.hi[k] = std::max(a0, std::max(a1, a2));
+                bp.c[k] = (bp.lo[k] + bp.hi[k]) * 0.5f;
+            }
+            bp.ref = 0x80000000u | (uint32_t)hb.pdata.size(); bp.surf = (uint32_t)i;
+            hb.pdata.push_back(make_float4(v0.x, v0.y, v0.z, e1.x));
+            hb.pdata.push_back(make_float4(e1.y, e1.z, e2.x, e2.y));
+            hb.pdata.push_back(make_float4(e2.z, 0.0f, 0.0f, 0.0f));
+            bprims.push_back(bp);
         } else if (s.geom == RT_GEOM_PLANE) {
             const H3 nraw = { s.g[0], s.g[1], s.g[2] };
             const float d = s.g[3];
@@ -261,20 +316,37 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             }
         } else {
             delete sc;
-            return fail(s.geom == RT_GEOM_TRIANGLE ? RT_E_UNSUPPORTED : RT_E_INVALID,
-                        "surface %lld: geometry %d is not supported by this build", (long long)i, s.geom);
+            return fail(RT_E_INVALID, "surface %lld: bad geometry %d", (long long)i, s.geom);
         }
         g.type = gtype;
+        g.index = (int32_t)i;
         int ns = default_samples(s.kind, s.sample_count, 0);
         if (s.kind == RT_KIND_LAMBERTIAN && s.sample_count == 0) sc->lamb_default.push_back((int)i);
         h.info = (uint32_t)s.kind | ((uint32_t)ns << 2) | ((uint32_t)gtype << 5);
-        geom[(size_t)i] = g;
+        // the scalar-operand linear list: every surface of a small scene, only the planes of a BVH scene
+        if (!use_bvh || s.geom == RT_GEOM_PLANE) geom.push_back(g);
         sc->h_shade[(size_t)i] = h;
+    }
+    sc->nloose = (int64_t)geom.size();
+    if (sc->nloose > kMaxPoolSurfaces) { delete sc; return fail(RT_E_UNSUPPORTED, "more than %d planes", kMaxPoolSurfaces); }
+    if (use_bvh) {
+        bvh_build(bprims, hb);
+        if (hb.depth > kBvhStack - 2) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
+        sc->nnodes = (int)hb.nodes.size(); sc->bvh_depth = hb.depth;
     }
 
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_geom), sizeof(GeomRec) * (size_t)(n > 0 ? n : 1));
-    if (e == hipSuccess && n > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * (size_t)n, hipMemcpyHostToDevice);
+    const size_t ng = geom.size();
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_geom), sizeof(GeomRec) * (ng > 0 ? ng : 1));
+    if (e == hipSuccess && ng > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * ng, hipMemcpyHostToDevice);
+    if (use_bvh && !hb.nodes.empty()) {
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), sizeof(BvhNode) * hb.nodes.size());
+        if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), sizeof(BvhNode) * hb.nodes.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_prims), sizeof(uint2) * hb.prims.size());
+        if (e == hipSuccess) e = hipMemcpy(sc->d_prims, hb.prims.data(), sizeof(uint2) * hb.prims.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_pdata), sizeof(float4) * hb.pdata.size());
+        if (e == hipSuccess) e = hipMemcpy(sc->d_pdata, hb.pdata.data(), sizeof(float4) * hb.pdata.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_status), sizeof(int));
     if (e == hipSuccess) e = hipMemset(sc->d_status, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_counter), sizeof(unsigned long long));
@@ -298,6 +370,9 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_counter) (void)hipFree(sc->d_counter);
     if (sc->d_accum) (void)hipFree(sc->d_accum);
     if (sc->d_spill) (void)hipFree(sc->d_spill);
+    if (sc->d_nodes) (void)hipFree(sc->d_nodes);
+    if (sc->d_prims) (void)hipFree(sc->d_prims);
+    if (sc->d_pdata) (void)hipFree(sc->d_pdata);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
     delete sc;
 }
@@ -314,8 +389,6 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
 
     const int ncols = (p->x_end - p->x_begin + p->x_step - 1) / p->x_step;
     if (ncols <= 0) return RT_OK;
-    if (sc->n > kMaxPoolSurfaces)
-        return fail(RT_E_UNSUPPORTED, "the linear-scan kernel handles at most %d surfaces (got %lld)", kMaxPoolSurfaces, (long long)sc->n);
     const long long npix = (long long)ncols * p->height;
     if (npix > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
     const int lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
@@ -340,7 +413,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
         c.scatter = (unsigned int)(m % (unsigned long long)npix);
         if (npix == 1) c.scatter = 0;
     }
-    a.nsurf = (int)sc->n; c.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
+    a.nsurf = (int)sc->nloose; c.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
     c.jitter = p->jitter ? 1 : 0;
     a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
     c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
@@ -365,15 +438,20 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     c.tan_half = tanf(cam->fov / 2.0f);
 
     const bool node64 = p->max_trace_depth > 13;
-    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)(node64 ? 12 : 11) * 64 * a.nblk);
+    const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
+    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * kBvhStack : 0));
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(sc->d_accum, 0, (size_t)npix * 4 * sizeof(unsigned long long), stream));
     if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
-    rc = node64 ? launch_trace<true>(sc, c, a, shade, p->waves_per_cu, smem, stream)
-                : launch_trace<false>(sc, c, a, shade, p->waves_per_cu, smem, stream);
+    if (sc->use_bvh)
+        rc = node64 ? launch_trace<true, true>(sc, c, a, shade, p->waves_per_cu, smem, stream)
+                    : launch_trace<false, true>(sc, c, a, shade, p->waves_per_cu, smem, stream);
+    else
+        rc = node64 ? launch_trace<true, false>(sc, c, a, shade, p->waves_per_cu, smem, stream)
+                    : launch_trace<false, false>(sc, c, a, shade, p->waves_per_cu, smem, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, sc->d_accum, d_rgba,
                        npix, p->spp);
@@ -441,8 +519,8 @@ int rt_find_closest(rt_scene* sc, int64_t nrays, const float* origins, const flo
     HIP_TRY(hipMemcpy(d_d, directions, n * 12, hipMemcpyHostToDevice));
     const long long blocks = ((long long)n + 255) / 256;
     if (blocks > 0x7fffffffLL) return fail(RT_E_INVALID, "too many rays for one launch");
-    hipLaunchKernelGGL(find_closest_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, sc->d_geom, (int)sc->n,
-                       (long long)n, d_o, d_d, d_t, d_i);
+    hipLaunchKernelGGL(find_closest_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, sc->d_geom, (int)sc->nloose,
+                       bvh_ref(sc), (long long)n, d_o, d_d, d_t, d_i);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost));

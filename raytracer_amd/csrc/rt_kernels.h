@@ -22,6 +22,7 @@
 // Records stay sorted by tree level (deepest on top), which bounds the pool to 64 records per
 // level — see DESIGN.md "Pool bound".
 #pragma once
+#include "rt_bvh.h"
 #include "rt_device.h"
 
 namespace rt {
@@ -67,7 +68,7 @@ RT_DEV const ColdArgs* cold_args()
 
 // meta word of a record
 //   bits 0..7 slot | 8..12 level | 13..15 children | 16..17 kind | 18..19 geometry type | 20..31 surface index
-constexpr int kMaxPoolSurfaces = 4096;
+constexpr int kMaxPoolSurfaces = 4096;   // surface index bits of the meta word (linear-scan scenes)
 RT_DEV uint32_t make_meta(int slot, int level, int n, int kind, int geom, int surf)
 {
     return (uint32_t)slot | ((uint32_t)level << 8) | ((uint32_t)n << 13) | ((uint32_t)kind << 16) |
@@ -100,14 +101,16 @@ constexpr int kLdsMap = kLdsPend + kSlots;       // u32 [64]        lane map (ch
 constexpr int kLdsPool = kLdsMap + 64;           // records, in blocks of 64
 
 // NODE64 = keep the ray-tree node index in 64 bits (needed when max_trace_depth > 13).
-template <bool NODE64>
+// BVH    = large scene: `geom` holds only the loose surfaces (planes), spheres and triangles are reached
+//          through `bvh` (rt_bvh.h); surface indices no longer fit the meta word and get their own field.
+template <bool NODE64, bool BVH>
 __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, const RenderArgs a,
                                                    const GeomRec* __restrict__ geom,
-                                                   const ShadeRec* __restrict__ shade)
+                                                   const ShadeRec* __restrict__ shade, const BvhRef bvh)
 {
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
-    constexpr int NF = NODE64 ? 12 : 11;
+    constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     unsigned long long* sl_acc = reinterpret_cast<unsigned long long*>(smem + kLdsAcc);
     unsigned long long* sl_ps = reinterpret_cast<unsigned long long*>(smem + kLdsPs);
     uint32_t* sl_pix = smem + kLdsPix;
@@ -129,7 +132,8 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         return pool + (b * (NF * 64) + (r & 63));
     };
     enum { F_PX = 0, F_PY = 64, F_PZ = 128, F_DX = 192, F_DY = 256, F_DZ = 320, F_BX = 384, F_BY = 448, F_BZ = 512,
-           F_META = 576, F_NODE = 640, F_NODEHI = 704 };
+           F_META = 576, F_NODE = 640, F_NODEHI = 704, F_SURF = NODE64 ? 768 : 704 };
+    uint32_t* bvh_stack = pool + a.nblk * (NF * 64) + lane;          // [kBvhStack][64], only when BVH
 
     const int spp = a.spp;
     const unsigned long long t_start = __builtin_readcyclecounter();
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     unsigned long long res_next = 0;            // first pixel-sample of the current refill
     bool exhausted = false;                     // the global counter has run past the end
     uint32_t nrays = 0;                         // closest-hit queries by this lane
+    uint32_t n_nodes = 0, n_prims = 0;          // BVH nodes visited / primitives tested by this lane
     float maxd = 0.0f;
     bool overflow = false;
     uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             slot = meta & 0xff;
             const int level = (meta >> 8) & 31, n = (meta >> 13) & 7;
             const int kind = (meta >> 16) & 3, gty = (meta >> 18) & 3;
-            const uint32_t surf = meta >> 20;
+            const uint32_t surf = BVH ? rb[F_SURF] : (meta >> 20);
             clevel = level + 1;
             ckind = kind;
             cnode = NODE64 ? 4ull * node + (uint64_t)child + 1ull : (uint64_t)(4u * (uint32_t)node + (uint32_t)child + 1u);
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         if (alive) {
             float t;
             closest_hit(geom, a.nsurf, O, Dn, hidx, t);
+            if (BVH) closest_hit_bvh(bvh, O, Dn, bvh_stack, 64, t, hidx, n_nodes, n_prims);
             nrays++;
             bool hit = hidx >= 0;
             float4 em = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -376,7 +382,8 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
                 hinfo = __float_as_uint(em.w);
                 // Scene.fs:79: the primary's closest candidate is re-tested with dotView; planes then
                 // cull at TMax/dotView (Plane.fs:46).  A failed re-test is a miss, not the next hit.
-                if (is_prim && ((hinfo >> 5) & 3) != kGeomSphere) hit = t <= (kTMax / dot_view);
+                const uint32_t hg = (hinfo >> 5) & 3;
+                if (is_prim && (hg == kGeomPlaneInf || hg == kGeomPlaneRect)) hit = t <= (kTMax / dot_view);
             }
             if (is_prim && prim_first) {                               // Scene.fs:80 / :29
                 const ColdArgs* ca = cold_args();
@@ -425,7 +432,8 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
                 wb[F_PX] = __float_as_uint(P.x); wb[F_PY] = __float_as_uint(P.y); wb[F_PZ] = __float_as_uint(P.z);
                 wb[F_DX] = __float_as_uint(Dn.x); wb[F_DY] = __float_as_uint(Dn.y); wb[F_DZ] = __float_as_uint(Dn.z);
                 wb[F_BX] = __float_as_uint(beta.x); wb[F_BY] = __float_as_uint(beta.y); wb[F_BZ] = __float_as_uint(beta.z);
-                wb[F_META] = make_meta(slot, clevel, (hinfo >> 2) & 7, hinfo & 3, (hinfo >> 5) & 3, hidx);
+                wb[F_META] = make_meta(slot, clevel, (hinfo >> 2) & 7, hinfo & 3, (hinfo >> 5) & 3, BVH ? 0 : hidx);
+                if (BVH) wb[F_SURF] = (uint32_t)hidx;
                 wb[F_NODE] = (uint32_t)cnode;
                 if (NODE64) wb[F_NODEHI] = (uint32_t)(cnode >> 32);
                 atomicAdd(&sl_pend[slot], 1u);
@@ -466,11 +474,13 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     const ColdArgs* ca = cold_args();
     unsigned long long* stats = ca->stats;
     if (stats) {
-        unsigned long long r = nrays;
+        unsigned long long r = nrays, nn = n_nodes, np = n_prims;
         float m = maxd;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             r += __shfl_xor(r, off);
+            nn += __shfl_xor(nn, off);
+            np += __shfl_xor(np, off);
             m = fmaxf(m, __shfl_xor(m, off));
         }
         if (lane == 0) {
@@ -482,6 +492,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             atomicAdd(stats + 5, (unsigned long long)n_diel);
             atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
+            if (BVH) { atomicAdd(stats + 8, nn); atomicAdd(stats + 9, np); }
         }
     }
     if (overflow && lane == 0) atomicExch(ca->status, 1);
@@ -504,14 +515,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* 
 }
 
 // findClosestIntersection as a batch query (Surface.fs:49-58): one ray per thread.
-__global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __restrict__ geom, int nsurf, long long nrays,
+__global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __restrict__ geom, int nsurf, const BvhRef bvh,
+                                                           long long nrays,
                                                            const float* __restrict__ o, const float* __restrict__ d,
                                                            float* __restrict__ t_out, int* __restrict__ idx_out)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= nrays) return;
     int idx; float t;
-    closest_hit(geom, nsurf, F3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), F3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), idx, t);
+    const f3 O = F3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), D = F3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    closest_hit(geom, nsurf, O, D, idx, t);
+    uint32_t stack[kBvhStack];
+    uint32_t nn = 0, np = 0;
+    closest_hit_bvh(bvh, O, D, stack, 1, t, idx, nn, np);
     t_out[i] = t; idx_out[i] = idx;
 }
 

@@ -194,6 +194,18 @@ class Plane:
             s.g[8], s.g[9] = f32(self.Width), f32(self.Height)
 
 
+class Triangle:
+    """A triangle Hitable.  NOT in the reference (Geometry/AABB.fs is empty, there is no triangle type): the
+    build's own primitive obeying the Hitable contract of Geometry/Core.fs:26-43 (include/rt_abi.h)."""
+
+    def __init__(self, v0, v1, v2):
+        self.V0, self.V1, self.V2 = (np.asarray(v, dtype=np.float32) for v in (v0, v1, v2))
+
+    def flatten(self, s):
+        s.geom = abi.GEOM_TRIANGLE
+        s.g[0:9] = [*self.V0, *self.V1, *self.V2]
+
+
 # ---------------------------------------------------------------------------------------------
 # Surface.fs
 # ---------------------------------------------------------------------------------------------
@@ -237,7 +249,11 @@ class Dielectric(Surface):
 
 
 def flatten_surfaces(surfaces):
-    """`Surface list -> rt_surface[]` (what `scene_spheres |> Array.ofList` becomes, Scene.fs:33)."""
+    """`Surface list -> rt_surface[]` (what `scene_spheres |> Array.ofList` becomes, Scene.fs:33).
+    A numpy array of dtype `abi.surface_dtype` (bulk-generated scenes) is passed through as a pointer."""
+    if isinstance(surfaces, np.ndarray):
+        assert surfaces.dtype == abi.surface_dtype and surfaces.flags["C_CONTIGUOUS"]
+        return surfaces.ctypes.data_as(C.POINTER(abi.rt_surface))
     arr = (abi.rt_surface * max(len(surfaces), 1))()
     for i, s in enumerate(surfaces):
         arr[i] = s.flatten() if isinstance(s, Surface) else s

@@ -18,7 +18,10 @@ class Scene:
     def __init__(self, surfaces=None, width=800, height=640, samplesPerPixel=1, maxTraceDepth=5,
                  backgroundColor=(0.0, 0.0, 0.0), cameraOriginWS=(-3.0, 6.0, 15.0), lookAt=(-1.0, 1.0, -10.0),
                  fov=None, seed=1, jitter=1, lambertian_samples=0, device=0, waves_per_cu=0, pool_blocks=0):
-        self.surfaces = list(host.SceneDefinitions.scene_spheres if surfaces is None else surfaces)   # Scene.fs:33
+        if isinstance(surfaces, np.ndarray):
+            self.surfaces = np.ascontiguousarray(surfaces)          # flat rt_surface records (raytracer_amd.scenes)
+        else:
+            self.surfaces = list(host.SceneDefinitions.scene_spheres if surfaces is None else surfaces)   # Scene.fs:33
         self.width, self.height = int(width), int(height)                                             # Scene.fs:18-19
         self.samplesPerPixel, self.maxTraceDepth = int(samplesPerPixel), int(maxTraceDepth)           # Scene.fs:20,31
         self.backgroundColor = tuple(backgroundColor)                                                 # Scene.fs:32

@@ -66,7 +66,7 @@ def f3(v):
 def render(surfaces, cam, params, flags=0, nthreads=0):
     """Oracle render. Returns dict(rgba[ncols,H,4], depth[ncols,H], ids[ncols,H], max_depth, rays)."""
     lib = load()
-    arr = host.flatten_surfaces(surfaces) if isinstance(surfaces, (list, tuple)) else surfaces
+    arr = host.flatten_surfaces(surfaces) if isinstance(surfaces, (list, tuple, np.ndarray)) else surfaces
     n = len(surfaces)
     ncols, H = host.num_columns(params), params.height
     rgba = np.empty((ncols, H, 4), dtype=np.float32)
@@ -83,7 +83,7 @@ def render(surfaces, cam, params, flags=0, nthreads=0):
 def find_closest(surfaces, origins, directions):
     """Oracle findClosestIntersection for a batch of rays. Returns (t, index)."""
     lib = load()
-    arr = host.flatten_surfaces(surfaces) if isinstance(surfaces, (list, tuple)) else surfaces
+    arr = host.flatten_surfaces(surfaces) if isinstance(surfaces, (list, tuple, np.ndarray)) else surfaces
     o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
     t = np.empty(len(o), dtype=np.float32)

@@ -1,0 +1,119 @@
+"""GPU parity for large scenes (BASELINE.json configs 3-5): triangle meshes and many spheres traced through
+the BVH must give exactly what the linear scan gives.  The oracle has no BVH: it is the brute-force
+linear scan of Surface.fs:49-58 extended with the build's triangle Hitable (no reference counterpart:
+Geometry/AABB.fs is empty), so parity here is against the build's own CPU restatement."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_amd import abi, host, scenes
+from raytracer_amd.scene import Scene
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+SD = host.SceneDefinitions
+
+
+def _records(surfaces):
+    arr = host.flatten_surfaces(surfaces)
+    return np.frombuffer(bytes(arr), dtype=abi.surface_dtype, count=len(surfaces)).copy()
+
+
+def _dense_spheres(n, seed):
+    s = scenes.many_spheres(n, seed=seed, environment=False)
+    s["g"][:, :3] *= np.float32(0.04)           # [-20,20] x [0,2] x [-40,0]: dense enough to bounce between spheres
+    s["g"][:, 1] -= np.float32(5.0)
+    return np.concatenate([s, scenes.reference_environment(1)])
+
+
+def test_small_mesh_render_matches_bruteforce_oracle():
+    m = scenes.heightfield_mesh(16)
+    _compare(Scene(surfaces=m, width=96, height=64, samplesPerPixel=2, maxTraceDepth=3, jitter=1, seed=3))
+
+
+def test_mixed_spheres_planes_triangles():
+    """config 4's scene shape: scene_spheres (all four kinds, bounded planes, lights) + a mesh, through the BVH."""
+    m = np.concatenate([_records(SD.scene_spheres), scenes.heightfield_mesh(12, environment=False, base=-5.9, amplitude=1.0)])
+    s = Scene(surfaces=m, width=120, height=90, samplesPerPixel=2, maxTraceDepth=4, jitter=1, seed=5)
+    _compare(s)
+    assert {20, 24, 25, 35, 1}.issubset(set(np.unique(s.objectIds).tolist())) and (s.objectIds >= 1000).any()
+
+
+def test_many_spheres_deep_single_path():
+    """config 5's shape: diffuse + metal + dielectric spheres, 16 bounces, Lambertian SampleCount 1."""
+    _compare(Scene(surfaces=_dense_spheres(3000, 42), width=96, height=64, samplesPerPixel=2, maxTraceDepth=16, jitter=1,
+                   seed=7, lambertian_samples=1, cameraOriginWS=(0.0, 6.0, 12.0), lookAt=(0.0, -4.0, -20.0)))
+
+
+def test_many_spheres_branching():
+    _compare(Scene(surfaces=_dense_spheres(1500, 9), width=64, height=48, samplesPerPixel=1, maxTraceDepth=3, jitter=1,
+                   seed=2, cameraOriginWS=(0.0, 6.0, 12.0), lookAt=(0.0, -4.0, -20.0)))
+
+
+def test_ties_resolve_to_lowest_index():
+    """Surface.fs:53 strict '<': of coincident surfaces the first in array order wins, also through the BVH."""
+    m = scenes.heightfield_mesh(8, environment=False)
+    dup = m.copy()
+    dup["id"] += 100000
+    both = np.concatenate([dup[::-1], m, scenes.reference_environment(1)])     # every triangle twice, interleaved order
+    s = Scene(surfaces=both, width=64, height=48, samplesPerPixel=1, maxTraceDepth=2, jitter=0)
+    _compare(s)
+    o = np.tile(np.array([[0.0, 5.0, 5.0]], dtype=np.float32), (4000, 1))
+    rng = np.random.default_rng(3)
+    tgt = np.stack([rng.uniform(-12, 12, 4000), np.full(4000, -4.0), rng.uniform(-26, -2, 4000)], axis=-1)
+    d = (tgt - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    t, idx = s.findClosestIntersection(o, d)
+    rt, ridx = O.find_closest(both, o, d)
+    assert np.array_equal(idx, ridx) and np.array_equal(t, rt)
+    hit = idx >= 0
+    assert hit.mean() > 0.5
+
+
+def test_find_closest_100k_triangle_mesh():
+    """config 3's mesh (100352 triangles): random rays, bit-exact t and index against the brute-force scan."""
+    m = scenes.heightfield_mesh(224)
+    assert (m["geom"] == abi.GEOM_TRIANGLE).sum() == 100352
+    rng = np.random.default_rng(11)
+    n = 6000
+    o = np.stack([rng.uniform(-14, 14, n), rng.uniform(-5, 8, n), rng.uniform(-28, 6, n)], axis=-1).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] -= 0.5
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    s = Scene(surfaces=m)
+    t, idx = s.findClosestIntersection(o, d)
+    rt, ridx = O.find_closest(m, o, d)
+    assert np.array_equal(idx, ridx) and np.array_equal(t, rt)
+    assert (m["geom"][idx[idx >= 0]] == abi.GEOM_TRIANGLE).mean() > 0.3
+
+
+def test_find_closest_one_million_spheres():
+    """config 5's scene at full size: the BVH over 1M spheres against the brute-force scan on 1500 rays."""
+    m = scenes.many_spheres(1_000_000)
+    rng = np.random.default_rng(12)
+    n = 1500
+    o = np.stack([rng.uniform(-400, 400, n), rng.uniform(0, 80, n), rng.uniform(-900, 50, n)], axis=-1).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] = -np.abs(d[:, 1]) * 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    s = Scene(surfaces=m)
+    t, idx = s.findClosestIntersection(o, d)
+    rt, ridx = O.find_closest(m, o, d)
+    assert np.array_equal(idx, ridx) and np.array_equal(t, rt)
+    assert (idx >= 0).mean() > 0.9 and (m["geom"][idx[idx >= 0]] == abi.GEOM_SPHERE).mean() > 0.3
+
+
+def test_c3_mesh_frame_properties():
+    """config 3 at full size (100k triangles, 800x640): primary visibility equals the batch closest-hit query,
+    the frame is finite, deterministic and independent of the column partition."""
+    m = scenes.heightfield_mesh(224)
+    s = Scene(surfaces=m, width=800, height=640, samplesPerPixel=1, maxTraceDepth=5, jitter=1, seed=1)
+    s.renderScene()
+    full, rays = s.frameBuffer.copy(), s.rayCount
+    assert np.isfinite(full).all() and (s.objectIds >= 1000).mean() > 0.3
+    tot = 0
+    for r in range(2):
+        rgba, depth, ids, md, n = s.renderColumns(r, s.width, 2)
+        assert np.array_equal(rgba, full[r::2]) and np.array_equal(ids, s.objectIds[r::2])
+        tot += n
+    assert tot == rays
