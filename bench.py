@@ -8,10 +8,13 @@ as N grows (strong scaling): value = rays of the whole frame / max-over-ranks ti
 
 A ray = one findClosestIntersection query (Surface.fs:49): primary + every bounce ray intersected.
 
-Workloads (BASELINE.json configs; scene = SceneDefinitions.scene_spheres, camera of Scene.fs:36-43):
-  c4s  3840x2160, 64 spp, maxTraceDepth 5, jitter on  — the "4K 64spp" of the metric (default)
-  c2   800x640, 16 spp, maxTraceDepth 4, jitter on    — configs[1]
-  c1   640x480, 1 spp, maxTraceDepth 5, pinhole       — configs[0]
+Workloads (BASELINE.json configs; camera of Scene.fs:36-43 unless noted):
+  c4   scene_spheres + 100k-triangle mesh, 3840x2160, 64 spp, maxTraceDepth 5  — configs[3], BVH (default)
+  c4s  scene_spheres only (12 surfaces, linear scan), 3840x2160, 64 spp, maxTraceDepth 5
+  c2   scene_spheres, 800x640, 16 spp, maxTraceDepth 4, jitter on    — configs[1]
+  c1   scene_spheres, 640x480, 1 spp, maxTraceDepth 5, pinhole       — configs[0]
+  c3   100k-triangle mesh + floor + lights, 800x640, 16 spp, maxTraceDepth 5     — configs[2], BVH
+  c5   1M spheres + floor + lights, 1920x1080, 4 spp, maxTraceDepth 16, Lambertian SampleCount 1 — configs[4], BVH
 """
 import argparse
 import json
@@ -25,10 +28,37 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 WORKLOADS = {
+    "c4": dict(width=3840, height=2160, samplesPerPixel=64, maxTraceDepth=5, jitter=1, seed=1),
+    "c3": dict(width=800, height=640, samplesPerPixel=16, maxTraceDepth=5, jitter=1, seed=1),
+    "c5": dict(width=1920, height=1080, samplesPerPixel=4, maxTraceDepth=16, jitter=1, seed=1, lambertian_samples=1),
     "c4s": dict(width=3840, height=2160, samplesPerPixel=64, maxTraceDepth=5, jitter=1, seed=1),
     "c2": dict(width=800, height=640, samplesPerPixel=16, maxTraceDepth=4, jitter=1, seed=1),
     "c1": dict(width=640, height=480, samplesPerPixel=1, maxTraceDepth=5, jitter=0, seed=1),
 }
+
+SCENE_NAMES = {"c4": "scene_spheres + 100352-triangle mesh (BVH)", "c3": "100352-triangle mesh + floor + 2 lights (BVH)",
+               "c5": "1M spheres + floor + 2 lights (BVH)"}
+_scene_cache = {}
+
+
+def workload_scene(wl):
+    """(surfaces or None for scene_spheres, extra Scene kwargs) of a workload."""
+    import numpy as np
+    from raytracer_amd import abi, host, scenes
+    if wl not in _scene_cache:
+        if wl == "c3":
+            _scene_cache[wl] = (scenes.heightfield_mesh(224), {})
+        elif wl == "c4":
+            arr = host.flatten_surfaces(host.SceneDefinitions.scene_spheres)
+            base = np.frombuffer(bytes(arr), dtype=abi.surface_dtype, count=12).copy()
+            mesh = scenes.heightfield_mesh(224, environment=False, base=-5.9, amplitude=1.2)
+            _scene_cache[wl] = (np.concatenate([base, mesh]), {})
+        elif wl == "c5":
+            _scene_cache[wl] = (scenes.many_spheres(1_000_000), dict(scenes.MANY_SPHERES_CAMERA))
+        else:
+            _scene_cache[wl] = (None, {})
+    return _scene_cache[wl]
+
 
 # Algorithmic FP32 work per ray, counted from the reference's F# (SURVEY.md section 8(d)); sqrt and
 # divide count 1.  Closest hit on scene_spheres = 6 sphere tests (27) + 6 plane tests (13) + 5
@@ -39,10 +69,19 @@ FLOPS_SCAN, FLOPS_LAMB, FLOPS_METAL, FLOPS_DIEL, FLOPS_PRIMARY = 437.0, 90.0, 60
 VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (packed FMA); plain f32 ops issue at a quarter of it
 
 
-def launch_flops(d):
+# BVH scenes: 20 flops per box test (two per node visit), 40 per triangle test, 27 per sphere
+# test, plus the loose planes scanned per ray; bytes: 64 per node visit, 8 + 48 per triangle, 8 + 16 per sphere.
+BVH_COST = {"c3": dict(scan=19.0 + 2 * 44.0, prim=40.0, prim_bytes=56.0), "c4": dict(scan=19.0 + 5 * 44.0, prim=40.0, prim_bytes=56.0),
+            "c5": dict(scan=19.0 + 2 * 44.0, prim=27.0, prim_bytes=24.0)}
+
+
+def launch_flops(d, wl="c4s"):
     prim = d["rays"] - d["lamb"] - d["metal"] - d["diel"]
-    return (FLOPS_SCAN * d["rays"] + FLOPS_LAMB * d["lamb"] + FLOPS_METAL * d["metal"] + FLOPS_DIEL * d["diel"]
-            + FLOPS_PRIMARY * prim)
+    gen = FLOPS_LAMB * d["lamb"] + FLOPS_METAL * d["metal"] + FLOPS_DIEL * d["diel"] + FLOPS_PRIMARY * prim
+    if wl in BVH_COST:
+        c = BVH_COST[wl]
+        return c["scan"] * d["rays"] + 40.0 * d["nodes"] + c["prim"] * d["prims"] + gen
+    return FLOPS_SCAN * d["rays"] + gen
 
 
 def measured_traffic(workload):
@@ -84,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c4s", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--pool-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,8 +153,10 @@ def main():
         torch.cuda.synchronize()
 
     def make(wl):
-        cfg = WORKLOADS[wl]
-        sc = Scene(device=local_rank, waves_per_cu=args.waves_per_cu, pool_blocks=args.pool_blocks, **cfg)
+        cfg = dict(WORKLOADS[wl])
+        surfaces, extra_kw = workload_scene(wl)
+        cfg.update(extra_kw)
+        sc = Scene(surfaces=surfaces, device=local_rank, waves_per_cu=args.waves_per_cu, pool_blocks=args.pool_blocks, **cfg)
         xb, xe, xs, ncols = multi.columns_of_rank(sc.width, rank, world)
         bufs = dict(
             rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
@@ -139,6 +180,7 @@ def main():
         rays = int(st[0].item())
         diag["rays"], diag["iters"] = rays, int(st[2].item())
         diag["lamb"], diag["metal"], diag["diel"], diag["sum_wave_clk"], diag["waves"] = (int(st[i].item()) for i in (3, 4, 5, 6, 7))
+        diag["nodes"], diag["prims"] = int(st[8].item()), int(st[9].item())
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
         return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
 
@@ -169,14 +211,15 @@ def main():
     out = None
     if rank == 0:
         cfg = WORKLOADS[args.workload]
-        flops = launch_flops(diag)                     # rank 0's last launch (interleaved columns: equal shares to <1 %)
+        flops = launch_flops(diag, args.workload)                     # rank 0's last launch (interleaved columns: equal shares to <1 %)
         achieved = flops / (kern_ms * 1e-3) / 1e12
         out = {
             "metric": "Mrays/s (primary+bounce)", "value": rays / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: scene_spheres (12 surfaces) %dx%d, %d spp, maxTraceDepth %d, jitter %d" % (
-                           args.workload, cfg["width"], cfg["height"], cfg["samplesPerPixel"], cfg["maxTraceDepth"], cfg["jitter"]),
+            "config": {"workload": "%s: %s, %dx%d, %d spp, maxTraceDepth %d, jitter %d" % (
+                           args.workload, SCENE_NAMES.get(args.workload, "scene_spheres (12 surfaces, linear scan)"),
+                           cfg["width"], cfg["height"], cfg["samplesPerPixel"], cfg["maxTraceDepth"], cfg["jitter"]),
                        "rays_per_frame": rays_per_frame, "partition": "interleaved columns, %d rank(s), RCCL gather to rank 0" % world},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / VALU_PEAK_TFLOPS, "traffic": measured_traffic(args.workload) if world == 1 else None,
@@ -184,16 +227,19 @@ def main():
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "flops_per_ray": flops / max(1, diag["rays"]),
                          "rays_by_kind": {"lambertian": diag["lamb"], "metal": diag["metal"], "dielectric": diag["diel"],
                                           "primary": diag["rays"] - diag["lamb"] - diag["metal"] - diag["diel"]},
+                         "bvh": ({"node_visits_per_ray": diag["nodes"] / max(1, diag["rays"]), "prim_tests_per_ray": diag["prims"] / max(1, diag["rays"]),
+                                  "fetch_GBps": (64.0 * diag["nodes"] + BVH_COST[args.workload]["prim_bytes"] * diag["prims"]) / (kern_ms * 1e-3) / 1e9}
+                                 if args.workload in BVH_COST else None),
                          "lane_fill": diag["rays"] / max(1, diag["iters"] * 64), "waves": diag["waves"],
                          "mean_wave_clk": diag["sum_wave_clk"] / max(1, diag["waves"])},
         }
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}
-        for wl in ("c1", "c2"):
+        for wl, st in (("c1", 20), ("c2", 20), ("c3", 5), ("c5", 3), ("c4s", 2)):
             if wl == args.workload:
                 continue
-            r, t, k, _ = run(wl, 20, 3)
-            extra[wl] = {"Mrays_per_s": r / t / 1e6, "ms_per_frame": t / 20 * 1e3, "kernel_ms": k, "rays_per_frame": r / 20}
+            r, t, k, _ = run(wl, st, 1)
+            extra[wl] = {"Mrays_per_s": r / t / 1e6, "ms_per_frame": t / st * 1e3, "kernel_ms": k, "rays_per_frame": r / st}
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

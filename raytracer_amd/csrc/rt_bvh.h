@@ -1,4 +1,4 @@
-// rt_bvh.h — closest hit through a flattened BVH in HBM (large scenes: triangle meshes, many spheres).
+// rt_bvh.h — closest hit through a flattened 4-wide BVH in HBM (large scenes: triangle meshes, many spheres).
 //
 // NOT in the reference: Geometry/AABB.fs is an empty module and findClosestIntersection is a linear scan
 // (Surface.fs:49-58).  The BVH only prunes: every primitive that the linear scan would accept is still
@@ -6,29 +6,29 @@
 // what "first in array order wins" (strict '<', Surface.fs:53) means.  So the result equals the linear
 // scan's bit for bit; tests compare against the brute-force oracle.
 //
-// Layout (built on the host, rt_bvh_build.h):
-//   nodes[]   32 B: lo.xyz, a | hi.xyz, b     inner: a = index of the left child (right = a+1), b = -1
-//                                             leaf : a = first primitive slot, b = primitive count (> 0)
-//             the two children of a node are adjacent, so one visit fetches both boxes as 64 contiguous bytes
-//   prims[]   uint2 per primitive slot (BVH order): x = type << 31 | float4 offset into pdata, y = surface index
-//   pdata[]   float4: sphere = (centre, r^2); triangle = (v0, e1.x) (e1.yz, e2.xy) (e2.z, 0, 0, 0)
+// Layout (built on the host, rt_bvh_build.h).  Traversal is bound by dependent, divergent memory requests
+// (measured with a binary tree of 32-byte nodes: 28 visits per ray, ~1.6 TB/s of 64-byte random reads,
+// 0.65 Grays/s on the 100k-triangle mesh), so a node holds FOUR child boxes in exactly one 128-byte line:
+//   nodes[]   8 float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] ref[4] pad
+//             ref: 0 = empty slot (its box lies at +infinity and is never hit); bit 31 set = leaf, (ref & 0x7fffffff) >> 3 = first primitive slot,
+//             ref & 7 = primitive count (1..4); otherwise the index of an inner node (never 0 = root)
+//   pdata[]   3 float4 per primitive slot, in BVH order so a leaf's records are contiguous:
+//             sphere   = (centre, r^2) (0,0,0,0)       (0,    surface index, 0, 0)
+//             triangle = (v0, e1.x)    (e1.yz, e2.xy)  (e2.z, surface index, 1, 0)
 // Boxes are padded on the host so that the (inexact) slab test never rejects a primitive the exact test hits.
 #pragma once
 #include "rt_device.h"
 
 namespace rt {
 
-struct BvhNode { float lo[3]; int a; float hi[3]; int b; };
-static_assert(sizeof(BvhNode) == 32, "BvhNode layout");
-
 struct BvhRef {
-    const float4* __restrict__ nodes;     // 2 float4 per node
-    const uint2* __restrict__ prims;
-    const float4* __restrict__ pdata;
+    const float4* __restrict__ nodes;     // 8 float4 per node
+    const float4* __restrict__ pdata;     // 3 float4 per primitive slot
     int nnodes;
 };
 
-constexpr int kBvhStack = 32;             // host guarantees tree depth <= kBvhStack - 2
+constexpr int kBvhLeafMax = 4;           // primitives per leaf (3 bits in a leaf ref)
+constexpr int kBvhStack = 32;             // host guarantees 3 * (tree depth) + 1 <= kBvhStack
 
 // (t, idx) is a better hit than (tmin, best): closer, or equally close with a lower array index
 RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
@@ -36,24 +36,25 @@ RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
     return ok & ((t < tmin) | ((t == tmin) & (idx < best)));
 }
 
-// slab test with NaN-ignoring min/max; returns the entry parameter, or a value > tmax when missed
-RT_DEV float box_entry(float4 lo, float4 hi, f3 O, f3 inv, float tmax)
+// Slab test; returns the entry parameter, or kFltMax when missed.  Inexact on purpose (boxes are padded):
+// (lo - O) / D is evaluated as fma(lo, 1/D, -O/D).  min/max ignore NaNs (0 * inf when a direction component
+// is 0), which only ever widens the test.  '<= tmax' keeps boxes that can only tie with the current hit: a
+// tie may still win on index.  Empty child slots are boxes at +infinity and always miss.
+RT_DEV float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 inv, f3 noi, float tmax)
 {
-    const float x0 = (lo.x - O.x) * inv.x, x1 = (hi.x - O.x) * inv.x;
-    const float y0 = (lo.y - O.y) * inv.y, y1 = (hi.y - O.y) * inv.y;
-    const float z0 = (lo.z - O.z) * inv.z, z1 = (hi.z - O.z) * inv.z;
+    const float x0 = __builtin_fmaf(lox, inv.x, noi.x), x1 = __builtin_fmaf(hix, inv.x, noi.x);
+    const float y0 = __builtin_fmaf(loy, inv.y, noi.y), y1 = __builtin_fmaf(hiy, inv.y, noi.y);
+    const float z0 = __builtin_fmaf(loz, inv.z, noi.z), z1 = __builtin_fmaf(hiz, inv.z, noi.z);
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
     return (tn <= tf) ? tn : kFltMax;
 }
 
-// One primitive against the ray: the same operations as the linear scan (Sphere.fs:18-43) / the
+// One primitive record against the ray: the same operations as the linear scan (Sphere.fs:18-43) / the
 // build's triangle Hitable (Moeller-Trumbore, see oracle/rt_oracle.c triangle_intersect).
-RT_DEV void prim_test(const float4* __restrict__ pdata, uint32_t ref, f3 O, f3 D, float& t, bool& ok)
+RT_DEV void prim_test(float4 a, float4 bb, float4 cc, f3 O, f3 D, float& t, bool& ok)
 {
-    const float4* p = pdata + (ref & 0x7fffffffu);
-    const float4 a = p[0];
-    if ((ref >> 31) == 0u) {
+    if (__float_as_uint(cc.z) == 0u) {
         const f3 ctr = O - F3(a.x, a.y, a.z);
         const float b = dot(ctr, D);
         const float C = dot(ctr, ctr) - a.w;
@@ -66,7 +67,6 @@ RT_DEV void prim_test(const float4* __restrict__ pdata, uint32_t ref, f3 O, f3 D
         t = ((i1 >= kTMin) & (i2 >= kTMin)) ? tboth : tone;
         ok = has & (t > kTMin);
     } else {
-        const float4 bb = p[1], cc = p[2];
         const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, bb.x, bb.y), e2 = F3(bb.z, bb.w, cc.x);
         const f3 pv = cross(D, e2);
         const float det = dot(e1, pv);
@@ -81,51 +81,76 @@ RT_DEV void prim_test(const float4* __restrict__ pdata, uint32_t ref, f3 O, f3 D
     }
 }
 
-// Depth-first traversal, near child first, far child on a per-lane stack (in `stack`, strided by
-// `stride` dwords so that lanes hit different LDS banks).  (tmin, idx) come in from the scan of the
-// loose surfaces (planes) and go out updated.
-RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, float& tmin, int& idx,
-                            uint32_t& nodes_visited, uint32_t& prims_tested)
+RT_DEV void sort2(float& ta, uint32_t& ra, float& tb, uint32_t& rb)
 {
-    if (bvh.nnodes == 0) return;
+    const bool sw = tb < ta;
+    const float t0 = sw ? tb : ta, t1 = sw ? ta : tb;
+    const uint32_t r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ta = t0; tb = t1; ra = r0; rb = r1;
+}
+
+constexpr uint32_t kBvhDone = 0xffffffffu;
+
+// Depth-first traversal, nearest child first, the other hit children on a per-lane stack (in `stack`,
+// strided by `stride` dwords so that lanes hit different LDS banks).  (tmin, idx) come in from the scan
+// of the loose surfaces (planes) and go out updated.
+//
+// Shape of the loop ("while-while"): all lanes of the wave first walk inner nodes until each has reached a
+// leaf (or finished), then the leaves are tested together.  A wave pays one memory latency per inner step
+// and one per leaf (all of a leaf's records are requested before the first is used), instead of the
+// inner + 2 x count dependent latencies per step of a single merged loop, which is what bounded the first version.
+RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, float& tmin, int& idx,
+                            uint32_t& cur, int& sp, int min_active, uint32_t& nodes_visited, uint32_t& prims_tested)
+{
     // reciprocal direction for the slab test only (not on the exact path): v_rcp_f32 is enough
     const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
-    int sp = 0;
-    int node = 0;
-    // the root is visited unconditionally (its children are tested below)
+    const f3 noi = F3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+    // `cur`/`sp` are the lane's traversal state: kBvhDone = no ray, 0 = at the root; a lane that is still
+    // walking when the call returns (fewer than min_active lanes were) continues in the next call.
     while (true) {
-        const float4 n0 = bvh.nodes[2 * node], n1 = bvh.nodes[2 * node + 1];
-        const int a = __float_as_int(n0.w), b = __float_as_int(n1.w);
-        nodes_visited++;
-        if (b > 0) {
-            for (int k = 0; k < b; k++) {
-                const uint2 pr = bvh.prims[a + k];
-                float t; bool ok;
-                prim_test(bvh.pdata, pr.x, O, D, t, ok);
-                prims_tested++;
-                const bool bt = better_hit(ok, t, (int)pr.y, tmin, idx);
-                tmin = bt ? t : tmin;
-                idx = bt ? (int)pr.y : idx;
-            }
-            node = -1;
-        } else {
-            const float4 l0 = bvh.nodes[2 * a], l1 = bvh.nodes[2 * a + 1];
-            const float4 r0 = bvh.nodes[2 * a + 2], r1 = bvh.nodes[2 * a + 3];
-            // '<= tmin' inside box_entry keeps boxes that can only tie: a tie may still win on index
-            const float tl = box_entry(l0, l1, O, inv, tmin);
-            const float tr = box_entry(r0, r1, O, inv, tmin);
-            const bool hl = tl < kFltMax, hr = tr < kFltMax;
-            if (hl & hr) {
-                const bool left_first = tl <= tr;
-                stack[sp * stride] = (uint32_t)(left_first ? a + 1 : a);
-                sp++;
-                node = left_first ? a : a + 1;
-            } else node = hl ? a : (hr ? a + 1 : -1);
+        const int nact = __popcll(__ballot(cur != kBvhDone));
+        if (nact == 0 || nact < min_active) break;
+        while ((int)cur >= 0) {
+            // ---- inner node: one 128-byte line, four slab tests
+            const float4* n = bvh.nodes + 8 * (size_t)cur;
+            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
+            nodes_visited++;
+            uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
+            float t0 = box_entry(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, inv, noi, tmin);
+            float t1 = box_entry(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, inv, noi, tmin);
+            float t2 = box_entry(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, inv, noi, tmin);
+            float t3 = box_entry(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, inv, noi, tmin);
+            // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
+            sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
+            // push far to near, descend into the nearest
+            if (t3 < kFltMax) { stack[sp * stride] = r3; sp++; }
+            if (t2 < kFltMax) { stack[sp * stride] = r2; sp++; }
+            if (t1 < kFltMax) { stack[sp * stride] = r1; sp++; }
+            if (t0 < kFltMax) cur = r0;
+            else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+            else cur = kBvhDone;
         }
-        if (node < 0) {
-            if (sp == 0) break;
-            sp--;
-            node = (int)stack[sp * stride];
+        if (cur != kBvhDone) {
+            // ---- leaf: 1..4 records of 3 float4, contiguous; request them all, then test in array order
+            const int first = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
+            float4 ra[kBvhLeafMax], rb[kBvhLeafMax], rc[kBvhLeafMax];
+#pragma unroll
+            for (int k = 0; k < kBvhLeafMax; k++) {
+                const float4* p = bvh.pdata + 3 * (size_t)(first + ((k < cnt) ? k : cnt - 1));
+                ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
+            }
+#pragma unroll
+            for (int k = 0; k < kBvhLeafMax; k++) {
+                float t; bool ok;
+                prim_test(ra[k], rb[k], rc[k], O, D, t, ok);
+                const int si = (int)__float_as_uint(rc[k].y);
+                const bool bt = better_hit(ok & (k < cnt), t, si, tmin, idx);
+                tmin = bt ? t : tmin;
+                idx = bt ? si : idx;
+            }
+            prims_tested += (uint32_t)cnt;
+            if (sp > 0) { sp--; cur = stack[sp * stride]; }
+            else cur = kBvhDone;
         }
     }
 }

@@ -1,34 +1,39 @@
 // rt_bvh_build.h — host-side BVH construction for large scenes (spheres and triangles; planes stay in the
-// linear list).  Not in the reference (Geometry/AABB.fs is empty).  Object-median splits along the longest
-// axis of the centroid bounds: perfectly balanced, so the per-lane traversal stack is bounded by
-// ceil(log2(n / leaf)) + 1, checked against kBvhStack.
+// linear list).  Not in the reference (Geometry/AABB.fs is empty).  A binary tree is built with object-median
+// splits along the longest axis of the centroid bounds (perfectly balanced: depth = ceil(log2(n/leaf)) + 1),
+// then collapsed into 4-wide nodes (rt_bvh.h): a node adopts its grandchildren until it has four children.
 #pragma once
 #include "rt_bvh.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 namespace rt {
 
 struct BuildPrim {
     float lo[3], hi[3], c[3];
-    uint32_t ref;       // type << 31 | float4 offset into pdata
+    uint32_t ref;       // type << 31 | float4 offset into the caller-order pdata
     uint32_t surf;      // index in the caller's surface array
 };
 
 struct HostBvh {
-    std::vector<BvhNode> nodes;
-    std::vector<uint2> prims;
-    std::vector<float4> pdata;
-    int depth = 0;
+    std::vector<float4> nodes;      // 8 per node
+    std::vector<float4> pdata;      // 3 per primitive slot, BVH order
+    int depth = 0;                  // depth of the 4-wide tree
 };
 
-constexpr int kBvhLeaf = 4;
+constexpr int kBvhLeaf = kBvhLeafMax;
 
-inline void bvh_bounds(const std::vector<BuildPrim>& p, size_t b, size_t e, float pad, BvhNode& n)
+struct BinNode { float lo[3], hi[3]; int left, right, first, count; };
+
+inline int bvh_bin_build(std::vector<BuildPrim>& p, size_t b, size_t e, float pad, std::vector<BinNode>& out)
 {
+    const int me = (int)out.size();
+    out.emplace_back();
+    BinNode n;
     for (int k = 0; k < 3; k++) { n.lo[k] = INFINITY; n.hi[k] = -INFINITY; }
     for (size_t i = b; i < e; i++)
         for (int k = 0; k < 3; k++) { n.lo[k] = std::min(n.lo[k], p[i].lo[k]); n.hi[k] = std::max(n.hi[k], p[i].hi[k]); }
@@ -39,50 +44,94 @@ inline void bvh_bounds(const std::vector<BuildPrim>& p, size_t b, size_t e, floa
         n.lo[k] = std::nextafter(n.lo[k] - pad, -INFINITY);
         n.hi[k] = std::nextafter(n.hi[k] + pad, INFINITY);
     }
-}
-
-inline void bvh_build_range(std::vector<BuildPrim>& p, size_t b, size_t e, int node, int depth, float pad, HostBvh& out)
-{
-    out.depth = std::max(out.depth, depth);
-    bvh_bounds(p, b, e, pad, out.nodes[node]);
-    const size_t n = e - b;
-    if (n <= (size_t)kBvhLeaf) {
-        out.nodes[node].a = (int)b;
-        out.nodes[node].b = (int)n;
-        return;
+    n.left = n.right = -1; n.first = (int)b; n.count = (int)(e - b);
+    if (e - b > (size_t)kBvhLeaf) {
+        float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (size_t i = b; i < e; i++)
+            for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], p[i].c[k]); chi[k] = std::max(chi[k], p[i].c[k]); }
+        int axis = 0;
+        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+        const size_t mid = b + (e - b) / 2;
+        std::nth_element(p.begin() + b, p.begin() + mid, p.begin() + e, [axis](const BuildPrim& x, const BuildPrim& y) {
+            return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.surf < y.surf);
+        });
+        n.count = 0;
+        n.left = bvh_bin_build(p, b, mid, pad, out);
+        n.right = bvh_bin_build(p, mid, e, pad, out);
     }
-    float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    for (size_t i = b; i < e; i++)
-        for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], p[i].c[k]); chi[k] = std::max(chi[k], p[i].c[k]); }
-    int axis = 0;
-    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
-    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
-    const size_t mid = b + n / 2;
-    std::nth_element(p.begin() + b, p.begin() + mid, p.begin() + e,
-                     [axis](const BuildPrim& x, const BuildPrim& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.surf < y.surf); });
-    const int left = (int)out.nodes.size();
-    out.nodes.emplace_back();
-    out.nodes.emplace_back();
-    out.nodes[node].a = left;
-    out.nodes[node].b = -1;
-    bvh_build_range(p, b, mid, left, depth + 1, pad, out);
-    bvh_build_range(p, mid, e, left + 1, depth + 1, pad, out);
+    out[me] = n;
+    return me;
 }
 
-// prims: one entry per sphere / triangle with its exact bounds; pdata already filled.
-inline void bvh_build(std::vector<BuildPrim>& prims, HostBvh& out)
+inline float bvh_area(const BinNode& n)
 {
-    out.nodes.clear(); out.prims.clear(); out.depth = 0;
+    const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// emits the 4-wide node for binary node `bn` at index `me` (already reserved); returns the subtree depth
+inline int bvh_collapse(const std::vector<BinNode>& bin, int bn, int me, HostBvh& out)
+{
+    int kids[4]; int nk = 0;
+    if (bin[bn].count > 0) kids[nk++] = bn;                 // a leaf root: one leaf child
+    else { kids[nk++] = bin[bn].left; kids[nk++] = bin[bn].right; }
+    while (nk < 4) {
+        int best = -1; float ba = -1.0f;
+        for (int i = 0; i < nk; i++)
+            if (bin[kids[i]].count == 0 && bvh_area(bin[kids[i]]) > ba) { ba = bvh_area(bin[kids[i]]); best = i; }
+        if (best < 0) break;
+        const int k = kids[best];
+        kids[best] = bin[k].left;
+        kids[nk++] = bin[k].right;
+    }
+    float f[32]; memset(f, 0, sizeof f);
+    uint32_t refs[4] = { 0, 0, 0, 0 };
+    int child_node[4] = { -1, -1, -1, -1 };
+    for (int i = 0; i < nk; i++) {
+        const BinNode& c = bin[kids[i]];
+        for (int k = 0; k < 3; k++) { f[4 * k + i] = c.lo[k]; f[12 + 4 * k + i] = c.hi[k]; }
+        if (c.count > 0) refs[i] = 0x80000000u | ((uint32_t)c.first << 3) | (uint32_t)c.count;
+        else {
+            child_node[i] = (int)(out.nodes.size() / 8);
+            refs[i] = (uint32_t)child_node[i];
+            out.nodes.resize(out.nodes.size() + 8);
+        }
+    }
+    for (int i = nk; i < 4; i++)                            // empty slots: a box at +infinity (never hit), ref 0
+        for (int k = 0; k < 3; k++) { f[4 * k + i] = INFINITY; f[12 + 4 * k + i] = INFINITY; }
+    memcpy(&f[24], refs, sizeof refs);
+    memcpy(&out.nodes[(size_t)me * 8], f, sizeof f);
+    int depth = 1;
+    for (int i = 0; i < nk; i++)
+        if (child_node[i] >= 0) depth = std::max(depth, 1 + bvh_collapse(bin, kids[i], child_node[i], out));
+    return depth;
+}
+
+// prims: one entry per sphere / triangle with its exact bounds and its data in `src_pdata` (caller order).
+inline void bvh_build(std::vector<BuildPrim>& prims, const std::vector<float4>& src_pdata, HostBvh& out)
+{
+    out.nodes.clear(); out.pdata.clear(); out.depth = 0;
     if (prims.empty()) return;
     float scale = 0.0f;
     for (const BuildPrim& p : prims)
         for (int k = 0; k < 3; k++) scale = std::max(scale, std::max(std::fabs(p.lo[k]), std::fabs(p.hi[k])));
     const float pad = 1e-5f * (scale + 1.0f);
-    out.nodes.reserve(prims.size());
-    out.nodes.emplace_back();
-    bvh_build_range(prims, 0, prims.size(), 0, 1, pad, out);
-    out.prims.resize(prims.size());
-    for (size_t i = 0; i < prims.size(); i++) { out.prims[i].x = prims[i].ref; out.prims[i].y = prims[i].surf; }
+    std::vector<BinNode> bin;
+    bin.reserve(prims.size());
+    bvh_bin_build(prims, 0, prims.size(), pad, bin);
+    out.nodes.reserve(prims.size() * 4);
+    out.nodes.resize(8);
+    out.depth = bvh_collapse(bin, 0, 0, out);
+    out.pdata.resize(3 * prims.size());
+    for (size_t i = 0; i < prims.size(); i++) {
+        const uint32_t src = prims[i].ref & 0x7fffffffu, type = prims[i].ref >> 31;
+        float4 a = src_pdata[src], b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
+        if (type) { b = src_pdata[src + 1]; c.x = src_pdata[src + 2].x; }
+        memcpy(&c.y, &prims[i].surf, 4);
+        memcpy(&c.z, &type, 4);
+        out.pdata[3 * i] = a; out.pdata[3 * i + 1] = b; out.pdata[3 * i + 2] = c;
+    }
 }
 
 }  // namespace rt

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -106,7 +107,7 @@ struct rt_scene {
     int num_cus = 0;
     int64_t nloose = 0;                        // entries of d_geom (all surfaces, or only the planes of a BVH scene)
     bool use_bvh = false;
-    float4* d_nodes = nullptr; uint2* d_prims = nullptr; float4* d_pdata = nullptr;
+    float4* d_nodes = nullptr; float4* d_pdata = nullptr;
     int nnodes = 0, bvh_depth = 0;
     int occ_smem[2] = { -1, -1 };              // LDS size the cached occupancy below was queried for
     int occ_per_cu[2] = { 0, 0 };
@@ -175,7 +176,7 @@ int ensure_spill(rt_scene* sc, size_t bytes)
 BvhRef bvh_ref(const rt_scene* sc)
 {
     BvhRef b;
-    b.nodes = sc->d_nodes; b.prims = sc->d_prims; b.pdata = sc->d_pdata; b.nnodes = sc->nnodes;
+    b.nodes = sc->d_nodes; b.pdata = sc->d_pdata; b.nnodes = sc->nnodes;
     return b;
 }
 
@@ -241,6 +242,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     const bool use_bvh = any_tri || n > kBvhThreshold;
     std::vector<BuildPrim> bprims;
     HostBvh hb;
+    std::vector<float4> src_pdata;
     if (use_bvh) bprims.reserve((size_t)nprim);
     rt_scene* sc = new (std::nothrow) rt_scene;
     if (!sc) return fail(RT_E_INVALID, "out of host memory");
@@ -266,8 +268,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
                 BuildPrim bp;
                 const float r = std::fabs(s.g[3]);
                 for (int k = 0; k < 3; k++) { bp.lo[k] = s.g[k] - r; bp.hi[k] = s.g[k] + r; bp.c[k] = s.g[k]; }
-                bp.ref = (uint32_t)hb.pdata.size(); bp.surf = (uint32_t)i;
-                hb.pdata.push_back(make_float4(g.a[0], g.a[1], g.a[2], g.a[3]));
+                bp.ref = (uint32_t)src_pdata.size(); bp.surf = (uint32_t)i;
+                src_pdata.push_back(make_float4(g.a[0], g.a[1], g.a[2], g.a[3]));
                 bprims.push_back(bp);
             }
         } else if (s.geom == RT_GEOM_TRIANGLE) {
@@ -284,10 +286,10 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
                 bp.lo[k] = std::min(a0, std::min(a1, a2)); bp.hi[k] = std::max(a0, std::max(a1, a2));
                 bp.c[k] = (bp.lo[k] + bp.hi[k]) * 0.5f;
             }
-            bp.ref = 0x80000000u | (uint32_t)hb.pdata.size(); bp.surf = (uint32_t)i;
-            hb.pdata.push_back(make_float4(v0.x, v0.y, v0.z, e1.x));
-            hb.pdata.push_back(make_float4(e1.y, e1.z, e2.x, e2.y));
-            hb.pdata.push_back(make_float4(e2.z, 0.0f, 0.0f, 0.0f));
+            bp.ref = 0x80000000u | (uint32_t)src_pdata.size(); bp.surf = (uint32_t)i;
+            src_pdata.push_back(make_float4(v0.x, v0.y, v0.z, e1.x));
+            src_pdata.push_back(make_float4(e1.y, e1.z, e2.x, e2.y));
+            src_pdata.push_back(make_float4(e2.z, 0.0f, 0.0f, 0.0f));
             bprims.push_back(bp);
         } else if (s.geom == RT_GEOM_PLANE) {
             const H3 nraw = { s.g[0], s.g[1], s.g[2] };
@@ -330,9 +332,9 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     sc->nloose = (int64_t)geom.size();
     if (sc->nloose > kMaxPoolSurfaces) { delete sc; return fail(RT_E_UNSUPPORTED, "more than %d planes", kMaxPoolSurfaces); }
     if (use_bvh) {
-        bvh_build(bprims, hb);
-        if (hb.depth > kBvhStack - 2) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
-        sc->nnodes = (int)hb.nodes.size(); sc->bvh_depth = hb.depth;
+        bvh_build(bprims, src_pdata, hb);
+        if (3 * hb.depth + 1 > kBvhStack) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
+        sc->nnodes = (int)(hb.nodes.size() / 8); sc->bvh_depth = hb.depth;
     }
 
     hipError_t e = hipSetDevice(device);
@@ -340,10 +342,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_geom), sizeof(GeomRec) * (ng > 0 ? ng : 1));
     if (e == hipSuccess && ng > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * ng, hipMemcpyHostToDevice);
     if (use_bvh && !hb.nodes.empty()) {
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), sizeof(BvhNode) * hb.nodes.size());
-        if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), sizeof(BvhNode) * hb.nodes.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_prims), sizeof(uint2) * hb.prims.size());
-        if (e == hipSuccess) e = hipMemcpy(sc->d_prims, hb.prims.data(), sizeof(uint2) * hb.prims.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), sizeof(float4) * hb.nodes.size());
+        if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), sizeof(float4) * hb.nodes.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_pdata), sizeof(float4) * hb.pdata.size());
         if (e == hipSuccess) e = hipMemcpy(sc->d_pdata, hb.pdata.data(), sizeof(float4) * hb.pdata.size(), hipMemcpyHostToDevice);
     }
@@ -371,7 +371,6 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_accum) (void)hipFree(sc->d_accum);
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes);
-    if (sc->d_prims) (void)hipFree(sc->d_prims);
     if (sc->d_pdata) (void)hipFree(sc->d_pdata);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
     delete sc;
@@ -418,6 +417,8 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
     c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
+    a.min_active = 32;
+    if (const char* e = getenv("RT_BVH_MIN_ACTIVE")) a.min_active = atoi(e);   // TUNING ONLY, to be removed
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
     // (DESIGN.md "Pool bound"); the top pool_blocks blocks live in LDS, the rest spills to HBM

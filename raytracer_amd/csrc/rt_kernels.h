@@ -57,6 +57,7 @@ struct RenderArgs {
     int nblk;                       // 64-record blocks of the pool kept in LDS
     int max_spill;                  // blocks one wave may spill to HBM (= record levels)
     uint32_t seed_lo, seed_hi;
+    int min_active;                 // BVH: leave the traversal when fewer lanes than this are still walking
 };
 
 RT_DEV const ColdArgs* cold_args()
@@ -150,6 +151,20 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     uint32_t n_lamb = 0, n_metal = 0, n_diel = 0;   // child rays intersected, by the kind that scattered them
     int spins = 0;
 
+    // Per-lane ray state.  In BVH mode a lane may keep its ray over several iterations: when most lanes of the
+    // wave have finished their traversal, the wave leaves the traversal loop, handles the finished rays,
+    // refills the free lanes with new rays and goes back in; the unfinished lanes ("busy") keep their
+    // registers and their traversal stack (measured before this: 16 % of the lanes active per VALU
+    // instruction, the wave waiting for its longest traversal).
+    f3 O = F3(0, 0, 0), Dn = F3(0, 0, 0), beta = F3(1.0f, 1.0f, 1.0f);
+    int slot = 0, clevel = 0; uint64_t cnode = 0;
+    bool alive = false, owner = false, is_prim = false;
+    float dot_view = 1.0f; uint32_t prim_o = 0; bool prim_first = false;
+    float tcur = 0.0f; int hidx = -1;
+    uint32_t trav_cur = kBvhDone; int trav_sp = 0;
+    bool busy = false;                          // BVH: this lane's traversal is suspended, not finished
+    unsigned long long busymask = 0ull;         // ballot(busy), wave-uniform
+
     while (true) {
         if (top == 0 && nspill > 0) {
             // ---- the LDS part of the pool is consumed: bring back the most recently spilled block
@@ -165,29 +180,31 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         int nchild = 0;
         uint32_t mp = 0u;
         const int top0 = top;
-        if (top > 0) {
+        const int nfree = BVH ? 64 - __popcll(busymask) : 64;       // lanes that can take a new ray
+        const int frank = BVH ? mbcnt64(~busymask) : lane;          // rank of this lane among the free lanes
+        if (top > 0 && nfree > 0) {
             const int ridx = top - 1 - lane;
             const uint32_t rmeta = (ridx >= 0) ? rec_base(ridx)[F_META] : 0u;
             const int rn = (rmeta >> 13) & 7;
             const unsigned long long b0 = __ballot(rn & 1), b1 = __ballot(rn & 2), b2 = __ballot(rn & 4);
             const int excl = mbcnt64(b0) + 2 * mbcnt64(b1) + 4 * mbcnt64(b2);
-            const bool take = rn > 0 && excl + rn <= 64;
+            const bool take = rn > 0 && excl + rn <= nfree;
             const unsigned long long tk = __ballot(take);
             nchild = __popcll(b0 & tk) + 2 * __popcll(b1 & tk) + 4 * __popcll(b2 & tk);
             if (take)
                 for (int c = 0; c < rn; c++) map[excl + c] = (uint32_t)(lane * 4 + c);
             __syncthreads();
-            if (lane < nchild) mp = map[lane];
+            if (!busy && frank < nchild) mp = map[frank];
             top -= __popcll(tk);
             __syncthreads();                    // map is reused for the slot allocation below
         }
         // ---- the pool is drained: start new pixel-samples in the free lanes
         int nprim = 0;
-        if (top == 0 && nspill == 0 && nchild < 64 && !exhausted) {
+        if (top == 0 && nspill == 0 && nchild < nfree && !exhausted) {
             // pull exactly as many pixel-samples as there are free lanes (and free slots): one returning
             // atomic per refill keeps the hand-out fine-grained, so no wave is left holding a queue of
             // expensive pixels while the others have finished
-            const int want = min(64 - nchild, __popcll(freemask));
+            const int want = min(nfree - nchild, __popcll(freemask));
             if (want > 0) {
                 const ColdArgs* ca = cold_args();
                 unsigned long long base = 0;
@@ -198,22 +215,24 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
                 else { res_next = base; nprim = (base + (unsigned long long)want <= total) ? want : (int)(total - base); }
             }
         }
-        if (nchild + nprim == 0) {
+        if (nchild + nprim == 0 && busymask == 0ull) {
             if (nspill > 0) continue;           // (cannot happen: a reloaded block always yields children)
             if (exhausted) break;               // nothing in the pool, nothing left to start
             if (++spins > 4) { overflow = true; break; }   // cannot happen (all slots are free here): never spin
             continue;
         }
         n_iter++; spins = 0;
-        const bool is_child = lane < nchild;
-        const bool is_prim = !is_child && lane < nchild + nprim;
-
-        f3 O = F3(0, 0, 0), Dn = F3(0, 0, 0), beta = F3(1.0f, 1.0f, 1.0f);
-        int slot = 0, clevel = 0; uint64_t cnode = 0;
+        const bool is_child = !busy && frank < nchild;
+        const bool fresh_prim = !busy && !is_child && frank < nchild + nprim;
         int ckind = 0;                          // kind of the surface this lane's child ray leaves (0 = primary)
-        bool alive = false;                     // this lane intersects a ray
-        bool owner = false;                     // this lane retires one pending unit of its slot
-        float dot_view = 1.0f; uint32_t prim_o = 0; bool prim_first = false;
+        if (!busy) {
+            O = F3(0, 0, 0); Dn = F3(0, 0, 0); beta = F3(1.0f, 1.0f, 1.0f);
+            slot = 0; clevel = 0; cnode = 0;
+            alive = false;                      // this lane intersects a ray
+            owner = false;                      // this lane retires one pending unit of its slot
+            is_prim = fresh_prim;
+            dot_view = 1.0f; prim_o = 0; prim_first = false;
+        }
 
         if (nprim > 0) {
             // ---- slot allocation: the lane whose index is a free slot number offers it by rank
@@ -221,11 +240,11 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             if (offer) map[mbcnt64(freemask)] = (uint32_t)lane;
             freemask &= ~__ballot(offer);
             __syncthreads();
-            if (is_prim) {
+            if (fresh_prim) {
                 // ============ rayTraceBase: primary ray (Camera.fs:8-39, Scene.fs:98-102) ============
                 const ColdArgs* ca = cold_args();
-                slot = (int)map[lane - nchild];
-                const unsigned long long q = res_next + (unsigned long long)(lane - nchild);   // compact index
+                slot = (int)map[frank - nchild];
+                const unsigned long long q = res_next + (unsigned long long)(frank - nchild);  // compact index
                 const unsigned long long o64 = q / (unsigned long long)spp;
                 const int s = (int)(q - o64 * (unsigned long long)spp);
                 // Consecutive hand-outs go to pixels far apart in the image (a fixed bijection), so that every
@@ -278,7 +297,12 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             ckind = kind;
             cnode = NODE64 ? 4ull * node + (uint64_t)child + 1ull : (uint64_t)(4u * (uint32_t)node + (uint32_t)child + 1u);
             const uint64_t ps = sl_ps[slot];                      // the RNG counter
-            owner = (child == 0);
+            if (BVH) {
+                // every child lane holds a pending unit of its own (child 0 inherits the record's), because
+                // the children of one record may finish in different iterations
+                owner = true;
+                if (child == 0 && n > 1) atomicAdd(&sl_pend[slot], (uint32_t)(n - 1));
+            } else owner = (child == 0);
 
             const ShadeRec* sr = shade + surf;
             const float4 al = *reinterpret_cast<const float4*>(&sr->albedo[0]);
@@ -362,19 +386,29 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             }
         }
 
-        n_lamb += (uint32_t)__popcll(__ballot(alive && ckind == kKindLambert));
-        n_metal += (uint32_t)__popcll(__ballot(alive && ckind == kKindMetal));
-        n_diel += (uint32_t)__popcll(__ballot(alive && ckind == kKindDielectric));
+        n_lamb += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindLambert));
+        n_metal += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindMetal));
+        n_diel += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindDielectric));
 
         // ============ findClosestIntersection + hit handling, all 64 lanes ============
         bool push = false;
         f3 P = F3(0, 0, 0);
-        int hidx = -1; uint32_t hinfo = 0;
-        if (alive) {
-            float t;
-            closest_hit(geom, a.nsurf, O, Dn, hidx, t);
-            if (BVH) closest_hit_bvh(bvh, O, Dn, bvh_stack, 64, t, hidx, n_nodes, n_prims);
+        uint32_t hinfo = 0;
+        if (alive && !busy) {
+            closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
+            trav_cur = 0u; trav_sp = 0;         // BVH: start at the root
             nrays++;
+        }
+        if (BVH) {
+            // new and suspended rays walk the tree together; leave early only when other work can fill the lanes
+            const bool refill = top > 0 || nspill > 0 || !exhausted;
+            if (!alive) trav_cur = kBvhDone;
+            closest_hit_bvh(bvh, O, Dn, bvh_stack, 64, tcur, hidx, trav_cur, trav_sp, refill ? a.min_active : 0, n_nodes, n_prims);
+            busy = alive && trav_cur != kBvhDone;
+            busymask = __ballot(busy);
+        }
+        if (alive && !busy) {
+            const float t = tcur;
             bool hit = hidx >= 0;
             float4 em = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (hit) {
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         // ---- retire: every popped record and every primary gives back one pending unit of its slot
         //      (after this iteration's pushes, so the count reaches 0 only when the whole tree is done)
         bool done = false;
-        if (owner) done = atomicSub(&sl_pend[slot], 1u) == 1u;
+        if (owner && !busy) done = atomicSub(&sl_pend[slot], 1u) == 1u;
         unsigned long long dm = __ballot(done);
         if (dm) {
             // Finished pixel-samples are added to their pixels (order-independent integer adds).  The wave
@@ -527,7 +561,8 @@ __global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __rest
     closest_hit(geom, nsurf, O, D, idx, t);
     uint32_t stack[kBvhStack];
     uint32_t nn = 0, np = 0;
-    closest_hit_bvh(bvh, O, D, stack, 1, t, idx, nn, np);
+    uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0;
+    closest_hit_bvh(bvh, O, D, stack, 1, t, idx, cur, sp, 0, nn, np);
     t_out[i] = t; idx_out[i] = idx;
 }
 
