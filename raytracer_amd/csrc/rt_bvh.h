@@ -29,6 +29,7 @@ struct BvhRef {
 
 constexpr int kBvhLeafMax = 4;           // primitives per leaf (3 bits in a leaf ref)
 constexpr int kBvhStack = 32;             // host guarantees 3 * (tree depth) + 1 <= kBvhStack
+constexpr int kBvhRing = 16;              // entries of the stack kept in LDS by the render kernel
 
 // (t, idx) is a better hit than (tmin, best): closer, or equally close with a lower array index
 RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
@@ -91,29 +92,65 @@ RT_DEV void sort2(float& ta, uint32_t& ra, float& tb, uint32_t& rb)
 
 constexpr uint32_t kBvhDone = 0xffffffffu;
 
-// Depth-first traversal, nearest child first, the other hit children on a per-lane stack (in `stack`,
-// strided by `stride` dwords so that lanes hit different LDS banks).  (tmin, idx) come in from the scan
-// of the loose surfaces (planes) and go out updated.
+// Depth-first traversal, nearest child first, the other hit children on a per-lane stack.  (tmin, idx) come
+// in from the scan of the loose surfaces (planes) and go out updated.
 //
-// Shape of the loop ("while-while"): all lanes of the wave first walk inner nodes until each has reached a
-// leaf (or finished), then the leaves are tested together.  A wave pays one memory latency per inner step
-// and one per leaf (all of a leaf's records are requested before the first is used), instead of the
-// inner + 2 x count dependent latencies per step of a single merged loop, which is what bounded the first version.
-RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, float& tmin, int& idx,
-                            uint32_t& cur, int& sp, int min_active, uint32_t& nodes_visited, uint32_t& prims_tested)
+// Stack: the top K entries live at stack[(i % K) * stride] (LDS, one column per lane); with SPILL, older
+// entries are moved to the lane's column of a backing store in HBM (`backing()` returns its base, stride 64)
+// — LDS per wave decides how many waves a CU holds, and a stack deeper than K is rare.  Entries [lo, sp) are
+// in the ring, [0, lo) in the backing store.
+//
+// Shape of the loop: every round, the lanes at an inner node take one step; the lanes at a leaf wait until
+// at least `leaf_min` of them have gathered (or no lane is at an inner node), then test their leaves together:
+// a leaf costs ~3 inner steps of VALU work, too much to run for a handful of lanes.  The loads of both groups
+// are issued before either is used, so a round costs one memory latency.
+//
+// `cur`/`sp`/`lo` are the lane's traversal state: cur = kBvhDone: no ray, 0: at the root.  The call returns
+// when no lane is walking or fewer than `min_active` are; those continue in the next call.
+template <int K, bool SPILL, typename Backing>
+RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, Backing backing,
+                            float& tmin, int& idx, uint32_t& cur, int& sp, int& lo, int min_active, int leaf_min,
+                            uint32_t& nodes_visited, uint32_t& prims_tested)
 {
+    static_assert((K & (K - 1)) == 0, "ring size must be a power of two");
     // reciprocal direction for the slab test only (not on the exact path): v_rcp_f32 is enough
     const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
     const f3 noi = F3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
-    // `cur`/`sp` are the lane's traversal state: kBvhDone = no ray, 0 = at the root; a lane that is still
-    // walking when the call returns (fewer than min_active lanes were) continues in the next call.
+    auto push = [&](uint32_t v) {
+        if (SPILL && sp - lo == K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
+        stack[(sp & (K - 1)) * stride] = v;
+        sp++;
+    };
+    auto pop = [&]() -> uint32_t {
+        if (sp == 0) return kBvhDone;
+        sp--;
+        if (SPILL && sp < lo) { lo = sp; return backing()[sp * 64]; }
+        return stack[(sp & (K - 1)) * stride];
+    };
     while (true) {
-        const int nact = __popcll(__ballot(cur != kBvhDone));
-        if (nact == 0 || nact < min_active) break;
-        while ((int)cur >= 0) {
-            // ---- inner node: one 128-byte line, four slab tests
+        const bool in = (int)cur >= 0, lf = ((int)cur < 0) & (cur != kBvhDone);
+        const int n_in = __popcll(__ballot(in)), n_lf = __popcll(__ballot(lf));
+        if (n_in + n_lf == 0 || n_in + n_lf < min_active) break;
+        const bool do_leaf = lf & ((n_lf >= leaf_min) | (n_in == 0));
+        float4 lx, ly, lz, hx, hy, hz, rf;
+        float4 ra[kBvhLeafMax], rb[kBvhLeafMax], rc[kBvhLeafMax];
+        int cnt = 0;
+        if (in) {
             const float4* n = bvh.nodes + 8 * (size_t)cur;
-            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
+            lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
+        }
+        if (do_leaf) {
+            // 1..4 records of 3 float4, contiguous
+            const int first = (int)((cur & 0x7fffffffu) >> 3);
+            cnt = (int)(cur & 7u);
+#pragma unroll
+            for (int k = 0; k < kBvhLeafMax; k++) {
+                const float4* p = bvh.pdata + 3 * (size_t)(first + ((k < cnt) ? k : cnt - 1));
+                ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
+            }
+        }
+        if (in) {
+            // ---- inner node: four slab tests
             nodes_visited++;
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             float t0 = box_entry(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, inv, noi, tmin);
@@ -123,22 +160,13 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
             sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
             // push far to near, descend into the nearest
-            if (t3 < kFltMax) { stack[sp * stride] = r3; sp++; }
-            if (t2 < kFltMax) { stack[sp * stride] = r2; sp++; }
-            if (t1 < kFltMax) { stack[sp * stride] = r1; sp++; }
-            if (t0 < kFltMax) cur = r0;
-            else if (sp > 0) { sp--; cur = stack[sp * stride]; }
-            else cur = kBvhDone;
+            if (t3 < kFltMax) push(r3);
+            if (t2 < kFltMax) push(r2);
+            if (t1 < kFltMax) push(r1);
+            cur = (t0 < kFltMax) ? r0 : pop();
         }
-        if (cur != kBvhDone) {
-            // ---- leaf: 1..4 records of 3 float4, contiguous; request them all, then test in array order
-            const int first = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
-            float4 ra[kBvhLeafMax], rb[kBvhLeafMax], rc[kBvhLeafMax];
-#pragma unroll
-            for (int k = 0; k < kBvhLeafMax; k++) {
-                const float4* p = bvh.pdata + 3 * (size_t)(first + ((k < cnt) ? k : cnt - 1));
-                ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
-            }
+        if (do_leaf) {
+            // ---- leaf: test in array order
 #pragma unroll
             for (int k = 0; k < kBvhLeafMax; k++) {
                 float t; bool ok;
@@ -149,8 +177,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
                 idx = bt ? si : idx;
             }
             prims_tested += (uint32_t)cnt;
-            if (sp > 0) { sp--; cur = stack[sp * stride]; }
-            else cur = kBvhDone;
+            cur = pop();
         }
     }
 }

@@ -104,6 +104,8 @@ struct rt_scene {
     size_t accum_bytes = 0;
     uint32_t* d_spill = nullptr;               // pool blocks spilled by the persistent waves (grown on demand)
     size_t spill_bytes = 0;
+    uint32_t* d_gstack = nullptr;              // backing store of the BVH traversal stacks (grown on demand)
+    size_t gstack_bytes = 0;
     int num_cus = 0;
     int64_t nloose = 0;                        // entries of d_geom (all surfaces, or only the planes of a BVH scene)
     bool use_bvh = false;
@@ -173,6 +175,15 @@ int ensure_spill(rt_scene* sc, size_t bytes)
     return RT_OK;
 }
 
+int ensure_gstack(rt_scene* sc, size_t bytes)
+{
+    if (sc->gstack_bytes >= bytes) return RT_OK;
+    if (sc->d_gstack) { HIP_TRY(hipFree(sc->d_gstack)); sc->d_gstack = nullptr; sc->gstack_bytes = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_gstack), bytes));
+    sc->gstack_bytes = bytes;
+    return RT_OK;
+}
+
 BvhRef bvh_ref(const rt_scene* sc)
 {
     BvhRef b;
@@ -205,6 +216,12 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec*
     int rc = ensure_spill(sc, (size_t)grid * a.max_spill * NF * 64 * sizeof(uint32_t));
     if (rc) return rc;
     c.spill = sc->d_spill;
+    c.gstack = nullptr;
+    if (BVH) {
+        rc = ensure_gstack(sc, (size_t)grid * kBvhStack * 64 * sizeof(uint32_t));
+        if (rc) return rc;
+        c.gstack = sc->d_gstack;
+    }
     hipLaunchKernelGGL((trace_kernel<NODE64, BVH>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, shade,
                        bvh_ref(sc));
     HIP_TRY(hipGetLastError());
@@ -370,6 +387,7 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_counter) (void)hipFree(sc->d_counter);
     if (sc->d_accum) (void)hipFree(sc->d_accum);
     if (sc->d_spill) (void)hipFree(sc->d_spill);
+    if (sc->d_gstack) (void)hipFree(sc->d_gstack);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes);
     if (sc->d_pdata) (void)hipFree(sc->d_pdata);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
@@ -419,6 +437,8 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     a.min_active = 32;
     if (const char* e = getenv("RT_BVH_MIN_ACTIVE")) a.min_active = atoi(e);   // TUNING ONLY, to be removed
+    a.leaf_min = 16;
+    if (const char* e = getenv("RT_BVH_LEAF_MIN")) a.leaf_min = atoi(e);       // TUNING ONLY, to be removed
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
     // (DESIGN.md "Pool bound"); the top pool_blocks blocks live in LDS, the rest spills to HBM
@@ -440,7 +460,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
 
     const bool node64 = p->max_trace_depth > 13;
     const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
-    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * kBvhStack : 0));
+    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * kBvhRing : 0));
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));

@@ -49,6 +49,7 @@ struct ColdArgs {
     unsigned long long* stats;      // RT_STATS_WORDS u64, or null
     int* status;                    // overflow flag
     uint32_t* spill;                // [waves][max_spill][NF*64] pool blocks spilled to HBM
+    uint32_t* gstack;               // [waves][kBvhStack][64] backing store of the traversal stacks (BVH)
 };
 
 // Hot constants: live in SGPRs for the whole kernel.
@@ -58,6 +59,7 @@ struct RenderArgs {
     int max_spill;                  // blocks one wave may spill to HBM (= record levels)
     uint32_t seed_lo, seed_hi;
     int min_active;                 // BVH: leave the traversal when fewer lanes than this are still walking
+    int leaf_min;                   // BVH: lanes that must wait at a leaf before the leaves are tested
 };
 
 RT_DEV const ColdArgs* cold_args()
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     };
     enum { F_PX = 0, F_PY = 64, F_PZ = 128, F_DX = 192, F_DY = 256, F_DZ = 320, F_BX = 384, F_BY = 448, F_BZ = 512,
            F_META = 576, F_NODE = 640, F_NODEHI = 704, F_SURF = NODE64 ? 768 : 704 };
-    uint32_t* bvh_stack = pool + a.nblk * (NF * 64) + lane;          // [kBvhStack][64], only when BVH
+    uint32_t* bvh_stack = pool + a.nblk * (NF * 64) + lane;          // [kBvhRing][64], only when BVH
 
     const int spp = a.spp;
     const unsigned long long t_start = __builtin_readcyclecounter();
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     bool alive = false, owner = false, is_prim = false;
     float dot_view = 1.0f; uint32_t prim_o = 0; bool prim_first = false;
     float tcur = 0.0f; int hidx = -1;
-    uint32_t trav_cur = kBvhDone; int trav_sp = 0;
+    uint32_t trav_cur = kBvhDone; int trav_sp = 0, trav_lo = 0;
     bool busy = false;                          // BVH: this lane's traversal is suspended, not finished
     unsigned long long busymask = 0ull;         // ballot(busy), wave-uniform
 
@@ -396,14 +398,16 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         uint32_t hinfo = 0;
         if (alive && !busy) {
             closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
-            trav_cur = 0u; trav_sp = 0;         // BVH: start at the root
+            trav_cur = 0u; trav_sp = 0; trav_lo = 0;   // BVH: start at the root
             nrays++;
         }
         if (BVH) {
             // new and suspended rays walk the tree together; leave early only when other work can fill the lanes
             const bool refill = top > 0 || nspill > 0 || !exhausted;
             if (!alive) trav_cur = kBvhDone;
-            closest_hit_bvh(bvh, O, Dn, bvh_stack, 64, tcur, hidx, trav_cur, trav_sp, refill ? a.min_active : 0, n_nodes, n_prims);
+            auto backing = [&]() { return cold_args()->gstack + (size_t)blockIdx.x * (kBvhStack * 64) + lane; };
+            closest_hit_bvh<kBvhRing, true>(bvh, O, Dn, bvh_stack, 64, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
+                                            refill ? a.min_active : 0, a.leaf_min, n_nodes, n_prims);
             busy = alive && trav_cur != kBvhDone;
             busymask = __ballot(busy);
         }
@@ -561,8 +565,9 @@ __global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __rest
     closest_hit(geom, nsurf, O, D, idx, t);
     uint32_t stack[kBvhStack];
     uint32_t nn = 0, np = 0;
-    uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0;
-    closest_hit_bvh(bvh, O, D, stack, 1, t, idx, cur, sp, 0, nn, np);
+    uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0, lo = 0;
+    auto backing = []() -> uint32_t* { return nullptr; };
+    closest_hit_bvh<kBvhStack, false>(bvh, O, D, stack, 1, backing, t, idx, cur, sp, lo, 0, 1, nn, np);
     t_out[i] = t; idx_out[i] = idx;
 }
 
