@@ -181,6 +181,7 @@ def main():
         diag["rays"], diag["iters"] = rays, int(st[2].item())
         diag["lamb"], diag["metal"], diag["diel"], diag["sum_wave_clk"], diag["waves"] = (int(st[i].item()) for i in (3, 4, 5, 6, 7))
         diag["nodes"], diag["prims"] = int(st[8].item()), int(st[9].item())
+        diag["rounds_inner"], diag["rounds_leaf"] = int(st[10].item()), int(st[11].item())
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
         return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
 
@@ -228,7 +229,9 @@ def main():
                          "rays_by_kind": {"lambertian": diag["lamb"], "metal": diag["metal"], "dielectric": diag["diel"],
                                           "primary": diag["rays"] - diag["lamb"] - diag["metal"] - diag["diel"]},
                          "bvh": ({"node_visits_per_ray": diag["nodes"] / max(1, diag["rays"]), "prim_tests_per_ray": diag["prims"] / max(1, diag["rays"]),
-                                  "fetch_GBps": (64.0 * diag["nodes"] + BVH_COST[args.workload]["prim_bytes"] * diag["prims"]) / (kern_ms * 1e-3) / 1e9}
+                                  "fetch_GBps": (128.0 * diag["nodes"] + 48.0 * diag["prims"]) / (kern_ms * 1e-3) / 1e9,
+                                  "inner_rounds": diag["rounds_inner"], "leaf_rounds": diag["rounds_leaf"], "iterations": diag["iters"],
+                                  "lanes_per_inner_round": diag["nodes"] / max(1, diag["rounds_inner"])}
                                  if args.workload in BVH_COST else None),
                          "lane_fill": diag["rays"] / max(1, diag["iters"] * 64), "waves": diag["waves"],
                          "mean_wave_clk": diag["sum_wave_clk"] / max(1, diag["waves"])},

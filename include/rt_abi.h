@@ -50,7 +50,10 @@ extern "C" {
 #define RT_GEOM_PLANE      1   /* Geometry/Plane.fs:12                                       */
 #define RT_GEOM_TRIANGLE   2   /* not in the reference (Geometry/AABB.fs is empty); obeys the
                                   Hitable contract of Geometry/Core.fs:26-43: Moeller-Trumbore
-                                  hit, accepted when t > TMin, constant normal
+                                  hit in f32 whose cross and dot products are fused
+                                  multiply-adds (x*y - z*w = fma(x,y,-(z*w)); a.b =
+                                  fma(az,bz,fma(ay,by,ax*bx))), accepted when t > TMin,
+                                  constant normal
                                   Normalize((v1-v0) x (v2-v0)), never flipped.  Scenes with
                                   triangles or more than 64 surfaces are traced through a BVH
                                   built at rt_scene_create; results equal the linear scan's.  */

@@ -333,16 +333,23 @@ static void plane_intersect(const osurf *s, const ray_t *r, int *has, float *t)
  *   p = D x e2; det = e1.p; |det| < 1e-12 -> no hit; inv = 1/det; tv = O - v0; u = (tv.p)*inv;
  *   q = tv x e1; v = (D.q)*inv; hit iff u >= 0, v >= 0, u + v <= 1; t = (e2.q)*inv.
  * Acceptable like a sphere: has && t > TMin (no TMax).  Normal = Normalize(e1 x e2), never flipped. */
+/* cross and dot product with explicit fused multiply-adds in a fixed order: the triangle Hitable is this
+   build's own (the reference has none) and is DEFINED this way; rt_bvh.h cross_fma / dot_fma mirror it */
+static v3 tri_cross(v3 a, v3 b)
+{
+    return V3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static float tri_dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 static void triangle_intersect(const osurf *s, const ray_t *r, int *has, float *t)
 {
-    v3 p = v3_cross(r->d, s->te2);
-    float det = v3_dot(s->te1, p);
+    v3 p = tri_cross(r->d, s->te2);
+    float det = tri_dot(s->te1, p);
     float inv = 1.0f / det;
     v3 tv = v3_sub(r->o, s->tv0);
-    float u = v3_dot(tv, p) * inv;
-    v3 q = v3_cross(tv, s->te1);
-    float v = v3_dot(r->d, q) * inv;
-    *t = v3_dot(s->te2, q) * inv;
+    float u = tri_dot(tv, p) * inv;
+    v3 q = tri_cross(tv, s->te1);
+    float v = tri_dot(r->d, q) * inv;
+    *t = tri_dot(s->te2, q) * inv;
     *has = !(fabsf(det) < 1e-12f) && u >= 0.0f && v >= 0.0f && (u + v) <= 1.0f;
 }
 /* Hitable.Intersect dispatch */

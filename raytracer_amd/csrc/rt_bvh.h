@@ -37,22 +37,37 @@ RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
     return ok & ((t < tmin) | ((t == tmin) & (idx < best)));
 }
 
-// Slab test; returns the entry parameter, or kFltMax when missed.  Inexact on purpose (boxes are padded):
-// (lo - O) / D is evaluated as fma(lo, 1/D, -O/D).  min/max ignore NaNs (0 * inf when a direction component
-// is 0), which only ever widens the test.  '<= tmax' keeps boxes that can only tie with the current hit: a
-// tie may still win on index.  Empty child slots are boxes at +infinity and always miss.
-RT_DEV float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 inv, f3 noi, float tmax)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Slab tests of two boxes at once (v_pk_fma_f32); returns the entry parameters, kFltMax when missed.
+// Inexact on purpose (boxes are padded): (lo - O) / D is evaluated as fma(lo, 1/D, -O/D).  min/max ignore
+// NaNs (0 * inf when a direction component is 0), which only ever widens the test.  '<= tmax' keeps boxes
+// that can only tie with the current hit: a tie may still win on index.  Empty child slots are boxes at
+// +infinity and always miss.
+RT_DEV void box_entry2(v2f lox, v2f loy, v2f loz, v2f hix, v2f hiy, v2f hiz, f3 inv, f3 noi, float tmax, float& ta, float& tb)
 {
-    const float x0 = __builtin_fmaf(lox, inv.x, noi.x), x1 = __builtin_fmaf(hix, inv.x, noi.x);
-    const float y0 = __builtin_fmaf(loy, inv.y, noi.y), y1 = __builtin_fmaf(hiy, inv.y, noi.y);
-    const float z0 = __builtin_fmaf(loz, inv.z, noi.z), z1 = __builtin_fmaf(hiz, inv.z, noi.z);
-    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
-    return (tn <= tf) ? tn : kFltMax;
+    const v2f ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
+    const v2f nx = { noi.x, noi.x }, ny = { noi.y, noi.y }, nz = { noi.z, noi.z };
+    const v2f x0 = __builtin_elementwise_fma(lox, ix, nx), x1 = __builtin_elementwise_fma(hix, ix, nx);
+    const v2f y0 = __builtin_elementwise_fma(loy, iy, ny), y1 = __builtin_elementwise_fma(hiy, iy, ny);
+    const v2f z0 = __builtin_elementwise_fma(loz, iz, nz), z1 = __builtin_elementwise_fma(hiz, iz, nz);
+    const float tna = fmaxf(fmaxf(fminf(x0.x, x1.x), fminf(y0.x, y1.x)), fmaxf(fminf(z0.x, z1.x), 0.0f));
+    const float tfa = fminf(fminf(fmaxf(x0.x, x1.x), fmaxf(y0.x, y1.x)), fminf(fmaxf(z0.x, z1.x), tmax));
+    const float tnb = fmaxf(fmaxf(fminf(x0.y, x1.y), fminf(y0.y, y1.y)), fmaxf(fminf(z0.y, z1.y), 0.0f));
+    const float tfb = fminf(fminf(fmaxf(x0.y, x1.y), fmaxf(y0.y, y1.y)), fminf(fmaxf(z0.y, z1.y), tmax));
+    ta = (tna <= tfa) ? tna : kFltMax;
+    tb = (tnb <= tfb) ? tnb : kFltMax;
 }
 
+// a x b and a . b with explicit FMAs, in a fixed order (the CPU checker mirrors them with fmaf)
+RT_DEV f3 cross_fma(f3 a, f3 b)
+{
+    return F3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+RT_DEV float dot_fma(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+
 // One primitive record against the ray: the same operations as the linear scan (Sphere.fs:18-43) / the
-// build's triangle Hitable (Moeller-Trumbore, see oracle/rt_oracle.c triangle_intersect).
+// build's triangle Hitable (Moeller-Trumbore with explicit FMAs, include/rt_abi.h RT_GEOM_TRIANGLE).
 RT_DEV void prim_test(float4 a, float4 bb, float4 cc, f3 O, f3 D, float& t, bool& ok)
 {
     if (__float_as_uint(cc.z) == 0u) {
@@ -69,14 +84,16 @@ RT_DEV void prim_test(float4 a, float4 bb, float4 cc, f3 O, f3 D, float& t, bool
         ok = has & (t > kTMin);
     } else {
         const f3 v0 = F3(a.x, a.y, a.z), e1 = F3(a.w, bb.x, bb.y), e2 = F3(bb.z, bb.w, cc.x);
-        const f3 pv = cross(D, e2);
-        const float det = dot(e1, pv);
+        // the triangle Hitable is this build's own (the reference has none): it is DEFINED with fused
+        // multiply-adds, written out one by one (fmaf on a CPU gives the same roundings)
+        const f3 pv = cross_fma(D, e2);
+        const float det = dot_fma(e1, pv);
         const float inv = div_rn(1.0f, det);
         const f3 tv = O - v0;
-        const float u = dot(tv, pv) * inv;
-        const f3 q = cross(tv, e1);
-        const float v = dot(D, q) * inv;
-        t = dot(e2, q) * inv;
+        const float u = dot_fma(tv, pv) * inv;
+        const f3 q = cross_fma(tv, e1);
+        const float v = dot_fma(D, q) * inv;
+        t = dot_fma(e2, q) * inv;
         const bool has = !(fabsf(det) < 1e-12f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f);
         ok = has & (t > kTMin);
     }
@@ -95,7 +112,8 @@ constexpr uint32_t kBvhDone = 0xffffffffu;
 // Depth-first traversal, nearest child first, the other hit children on a per-lane stack.  (tmin, idx) come
 // in from the scan of the loose surfaces (planes) and go out updated.
 //
-// Stack: the top K entries live at stack[(i % K) * stride] (LDS, one column per lane); with SPILL, older
+// Stack: the top K entries live at stack[(i % K) * stride] (LDS, one column per lane, K + 1 rows: row K is a
+// write-only spare); with SPILL, older
 // entries are moved to the lane's column of a backing store in HBM (`backing()` returns its base, stride 64)
 // — LDS per wave decides how many waves a CU holds, and a stack deeper than K is rare.  Entries [lo, sp) are
 // in the ring, [0, lo) in the backing store.
@@ -110,32 +128,32 @@ constexpr uint32_t kBvhDone = 0xffffffffu;
 template <int K, bool SPILL, typename Backing>
 RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, Backing backing,
                             float& tmin, int& idx, uint32_t& cur, int& sp, int& lo, int min_active, int leaf_min,
-                            uint32_t& nodes_visited, uint32_t& prims_tested)
+                            uint32_t& nodes_visited, uint32_t& prims_tested, uint32_t& rounds_inner, uint32_t& rounds_leaf)
 {
     static_assert((K & (K - 1)) == 0, "ring size must be a power of two");
     // reciprocal direction for the slab test only (not on the exact path): v_rcp_f32 is enough
     const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
     const f3 noi = F3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
-    auto push = [&](uint32_t v) {
-        if (SPILL && sp - lo == K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
-        stack[(sp & (K - 1)) * stride] = v;
-        sp++;
-    };
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kBvhDone;
         sp--;
-        if (SPILL && sp < lo) { lo = sp; return backing()[sp * 64]; }
-        return stack[(sp & (K - 1)) * stride];
+        uint32_t v = stack[(sp & (K - 1)) * stride];
+        if (SPILL && sp < lo) { lo = sp; v = backing()[sp * 64]; }
+        return v;
     };
     while (true) {
         const bool in = (int)cur >= 0, lf = ((int)cur < 0) & (cur != kBvhDone);
         const int n_in = __popcll(__ballot(in)), n_lf = __popcll(__ballot(lf));
         if (n_in + n_lf == 0 || n_in + n_lf < min_active) break;
-        const bool do_leaf = lf & ((n_lf >= leaf_min) | (n_in == 0));
+        // a group steps when it is at least leaf_min lanes strong, the larger one in any case
+        const bool do_in = in & ((n_in >= leaf_min) | (n_in >= n_lf));
+        const bool do_leaf = lf & ((n_lf >= leaf_min) | (n_lf > n_in));
+        rounds_inner += __ballot(do_in) != 0ull ? 1u : 0u;      // wave-uniform statistics
+        rounds_leaf += __ballot(do_leaf) != 0ull ? 1u : 0u;
         float4 lx, ly, lz, hx, hy, hz, rf;
         float4 ra[kBvhLeafMax], rb[kBvhLeafMax], rc[kBvhLeafMax];
         int cnt = 0;
-        if (in) {
+        if (do_in) {
             const float4* n = bvh.nodes + 8 * (size_t)cur;
             lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
         }
@@ -149,20 +167,25 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
                 ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
             }
         }
-        if (in) {
+        if (do_in) {
             // ---- inner node: four slab tests
             nodes_visited++;
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
-            float t0 = box_entry(lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, inv, noi, tmin);
-            float t1 = box_entry(lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, inv, noi, tmin);
-            float t2 = box_entry(lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, inv, noi, tmin);
-            float t3 = box_entry(lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, inv, noi, tmin);
+            float t0, t1, t2, t3;
+            box_entry2(v2f{ lx.x, lx.y }, v2f{ ly.x, ly.y }, v2f{ lz.x, lz.y }, v2f{ hx.x, hx.y }, v2f{ hy.x, hy.y }, v2f{ hz.x, hz.y },
+                       inv, noi, tmin, t0, t1);
+            box_entry2(v2f{ lx.z, lx.w }, v2f{ ly.z, ly.w }, v2f{ lz.z, lz.w }, v2f{ hx.z, hx.w }, v2f{ hy.z, hy.w }, v2f{ hz.z, hz.w },
+                       inv, noi, tmin, t2, t3);
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
             sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
-            // push far to near, descend into the nearest
-            if (t3 < kFltMax) push(r3);
-            if (t2 < kFltMax) push(r2);
-            if (t1 < kFltMax) push(r1);
+            // the hits are a prefix of the sorted four: descend into the nearest, push the others far to
+            // near.  Branch-free: all three are stored, the misses into the spare row K of the ring.
+            const int nh = (t1 < kFltMax ? 1 : 0) + (t2 < kFltMax ? 1 : 0) + (t3 < kFltMax ? 1 : 0);
+            if (SPILL) while (sp + nh - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
+            stack[((nh >= 1) ? ((sp + nh - 1) & (K - 1)) : K) * stride] = r1;
+            stack[((nh >= 2) ? ((sp + nh - 2) & (K - 1)) : K) * stride] = r2;
+            stack[((nh >= 3) ? (sp & (K - 1)) : K) * stride] = r3;
+            sp += nh;
             cur = (t0 < kFltMax) ? r0 : pop();
         }
         if (do_leaf) {

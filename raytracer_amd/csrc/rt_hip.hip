@@ -435,10 +435,10 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
     c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
+    // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
+    // half of its lanes still walk the tree; a group of lanes steps once 20 of them have gathered
     a.min_active = 32;
-    if (const char* e = getenv("RT_BVH_MIN_ACTIVE")) a.min_active = atoi(e);   // TUNING ONLY, to be removed
-    a.leaf_min = 16;
-    if (const char* e = getenv("RT_BVH_LEAF_MIN")) a.leaf_min = atoi(e);       // TUNING ONLY, to be removed
+    a.leaf_min = 20;
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
     // (DESIGN.md "Pool bound"); the top pool_blocks blocks live in LDS, the rest spills to HBM
@@ -460,7 +460,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
 
     const bool node64 = p->max_trace_depth > 13;
     const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
-    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * kBvhRing : 0));
+    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * (kBvhRing + 1) : 0));
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     bool exhausted = false;                     // the global counter has run past the end
     uint32_t nrays = 0;                         // closest-hit queries by this lane
     uint32_t n_nodes = 0, n_prims = 0;          // BVH nodes visited / primitives tested by this lane
+    uint32_t n_rin = 0, n_rlf = 0;              // BVH traversal rounds with an inner / a leaf step (wave-uniform)
     float maxd = 0.0f;
     bool overflow = false;
     uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             if (!alive) trav_cur = kBvhDone;
             auto backing = [&]() { return cold_args()->gstack + (size_t)blockIdx.x * (kBvhStack * 64) + lane; };
             closest_hit_bvh<kBvhRing, true>(bvh, O, Dn, bvh_stack, 64, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
-                                            refill ? a.min_active : 0, a.leaf_min, n_nodes, n_prims);
+                                            refill ? a.min_active : 0, a.leaf_min, n_nodes, n_prims, n_rin, n_rlf);
             busy = alive && trav_cur != kBvhDone;
             busymask = __ballot(busy);
         }
@@ -530,7 +531,10 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             atomicAdd(stats + 5, (unsigned long long)n_diel);
             atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
-            if (BVH) { atomicAdd(stats + 8, nn); atomicAdd(stats + 9, np); }
+            if (BVH) {
+                atomicAdd(stats + 8, nn); atomicAdd(stats + 9, np);
+                atomicAdd(stats + 10, (unsigned long long)n_rin); atomicAdd(stats + 11, (unsigned long long)n_rlf);
+            }
         }
     }
     if (overflow && lane == 0) atomicExch(ca->status, 1);
@@ -563,11 +567,11 @@ __global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __rest
     int idx; float t;
     const f3 O = F3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), D = F3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     closest_hit(geom, nsurf, O, D, idx, t);
-    uint32_t stack[kBvhStack];
+    uint32_t stack[kBvhStack + 1];
     uint32_t nn = 0, np = 0;
     uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0, lo = 0;
     auto backing = []() -> uint32_t* { return nullptr; };
-    closest_hit_bvh<kBvhStack, false>(bvh, O, D, stack, 1, backing, t, idx, cur, sp, lo, 0, 1, nn, np);
+    closest_hit_bvh<kBvhStack, false>(bvh, O, D, stack, 1, backing, t, idx, cur, sp, lo, 0, 1, nn, np, nn, np);
     t_out[i] = t; idx_out[i] = idx;
 }
 
