@@ -69,10 +69,10 @@ FLOPS_SCAN, FLOPS_LAMB, FLOPS_METAL, FLOPS_DIEL, FLOPS_PRIMARY = 437.0, 90.0, 60
 VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (packed FMA); plain f32 ops issue at a quarter of it
 
 
-# BVH scenes: 20 flops per box test (two per node visit), 40 per triangle test, 27 per sphere
-# test, plus the loose planes scanned per ray; bytes: 64 per node visit, 8 + 48 per triangle, 8 + 16 per sphere.
-BVH_COST = {"c3": dict(scan=19.0 + 2 * 44.0, prim=40.0, prim_bytes=56.0), "c4": dict(scan=19.0 + 5 * 44.0, prim=40.0, prim_bytes=56.0),
-            "c5": dict(scan=19.0 + 2 * 44.0, prim=27.0, prim_bytes=24.0)}
+# BVH scenes: 20 flops per box test (four per visit of a 4-wide node), 40 per triangle test, 27
+# per sphere test, plus the loose planes scanned per ray; bytes: 128 per node visit, 48 per primitive record.
+BVH_COST = {"c3": dict(scan=19.0 + 2 * 44.0, prim=40.0), "c4": dict(scan=19.0 + 5 * 44.0, prim=40.0),
+            "c5": dict(scan=19.0 + 2 * 44.0, prim=27.0)}
 
 
 def launch_flops(d, wl="c4s"):
@@ -80,7 +80,7 @@ def launch_flops(d, wl="c4s"):
     gen = FLOPS_LAMB * d["lamb"] + FLOPS_METAL * d["metal"] + FLOPS_DIEL * d["diel"] + FLOPS_PRIMARY * prim
     if wl in BVH_COST:
         c = BVH_COST[wl]
-        return c["scan"] * d["rays"] + 40.0 * d["nodes"] + c["prim"] * d["prims"] + gen
+        return c["scan"] * d["rays"] + 80.0 * d["nodes"] + c["prim"] * d["prims"] + gen
     return FLOPS_SCAN * d["rays"] + gen
 
 
