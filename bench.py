@@ -132,7 +132,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from raytracer_amd import multi
+    from raytracer_amd import abi, multi
     from raytracer_amd.scene import Scene
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,7 +161,7 @@ def main():
         bufs = dict(
             rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
             depth=torch.zeros((ncols, sc.height), dtype=torch.float32, device=dev),
-            stats=torch.zeros(12, dtype=torch.int64, device=dev),
+            stats=torch.zeros(abi.RT_STATS_WORDS, dtype=torch.int64, device=dev),
         )
         g = multi.FrameGatherer(sc.width, sc.height, dev, rank, world)
         return sc, (xb, xe, xs), bufs, g
@@ -182,6 +182,7 @@ def main():
         diag["lamb"], diag["metal"], diag["diel"], diag["sum_wave_clk"], diag["waves"] = (int(st[i].item()) for i in (3, 4, 5, 6, 7))
         diag["nodes"], diag["prims"] = int(st[8].item()), int(st[9].item())
         diag["rounds_inner"], diag["rounds_leaf"] = int(st[10].item()), int(st[11].item())
+        diag["phase_clk"] = [int(st[i].item()) for i in (12, 13, 14, 15)]
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
         return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
 
@@ -231,7 +232,8 @@ def main():
                          "bvh": ({"node_visits_per_ray": diag["nodes"] / max(1, diag["rays"]), "prim_tests_per_ray": diag["prims"] / max(1, diag["rays"]),
                                   "fetch_GBps": (128.0 * diag["nodes"] + 48.0 * diag["prims"]) / (kern_ms * 1e-3) / 1e9,
                                   "inner_rounds": diag["rounds_inner"], "leaf_rounds": diag["rounds_leaf"], "iterations": diag["iters"],
-                                  "lanes_per_inner_round": diag["nodes"] / max(1, diag["rounds_inner"])}
+                                  "lanes_per_inner_round": diag["nodes"] / max(1, diag["rounds_inner"]),
+                                  "phase_clk_gen_scan_trav_shade": diag["phase_clk"]}
                                  if args.workload in BVH_COST else None),
                          "lane_fill": diag["rays"] / max(1, diag["iters"] * 64), "waves": diag["waves"],
                          "mean_wave_clk": diag["sum_wave_clk"] / max(1, diag["waves"])},

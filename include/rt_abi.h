@@ -130,9 +130,11 @@ int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
  * of max depth (f32) in the low word, [2] 64-ray loop iterations over all waves, [3] / [4] / [5] child
  * rays scattered by Lambertian / Metal / Dielectric surfaces (ray count minus these = primary rays),
  * [6] summed wave lifetimes in shader clocks, [7] waves, [8] BVH nodes visited, [9] BVH primitives
- * tested (0 for linear-scan scenes), [10..11] reserved; may be NULL.
+ * tested (0 for linear-scan scenes), [10] / [11] BVH traversal rounds with an inner-node / a leaf step,
+ * [12..15] shader clocks summed over waves in the phases generate / plane scan / BVH traversal / shade+flush
+ * (BVH scenes only, filled by builds with -DRT_PHASE_TIMING, else 0); may be NULL.
  * No counterpart in the reference.                                                            */
-#define RT_STATS_WORDS 12
+#define RT_STATS_WORDS 16
 int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);
@@ -154,7 +156,7 @@ const char* rt_last_error(void);
 
 /* ABI version: bumped whenever a struct layout or signature changes.                         */
 int  rt_abi_version(void);
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 #ifdef __cplusplus
 }

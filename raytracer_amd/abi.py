@@ -19,7 +19,8 @@ RT_E_UNSUPPORTED = -5
 KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
-RT_ABI_VERSION = 4
+RT_ABI_VERSION = 5
+RT_STATS_WORDS = 16
 
 
 class rt_surface(C.Structure):

@@ -153,6 +153,12 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
     uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
     uint32_t n_lamb = 0, n_metal = 0, n_diel = 0;   // child rays intersected, by the kind that scattered them
     int spins = 0;
+#ifdef RT_PHASE_TIMING
+    unsigned long long ph_gen = 0, ph_scan = 0, ph_trav = 0, ph_shade = 0, ph_t = __builtin_readcyclecounter();
+#define RT_PHASE(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - ph_t; ph_t = now_; }
+#else
+#define RT_PHASE(acc)
+#endif
 
     // Per-lane ray state.  In BVH mode a lane may keep its ray over several iterations: when most lanes of the
     // wave have finished their traversal, the wave leaves the traversal loop, handles the finished rays,
@@ -397,11 +403,13 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
         bool push = false;
         f3 P = F3(0, 0, 0);
         uint32_t hinfo = 0;
+        RT_PHASE(ph_gen)
         if (alive && !busy) {
             closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
             trav_cur = 0u; trav_sp = 0; trav_lo = 0;   // BVH: start at the root
             nrays++;
         }
+        RT_PHASE(ph_scan)
         if (BVH) {
             // new and suspended rays walk the tree together; leave early only when other work can fill the lanes
             const bool refill = top > 0 || nspill > 0 || !exhausted;
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             busy = alive && trav_cur != kBvhDone;
             busymask = __ballot(busy);
         }
+        RT_PHASE(ph_trav)
         if (alive && !busy) {
             const float t = tcur;
             bool hit = hidx >= 0;
@@ -507,6 +516,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             }
         }
         __syncthreads();
+        RT_PHASE(ph_shade)
     }
 
     // ================= statistics ================================================================
@@ -534,6 +544,9 @@ __global__ __launch_bounds__(64) void trace_kernel(const ColdArgs cold_unused, c
             if (BVH) {
                 atomicAdd(stats + 8, nn); atomicAdd(stats + 9, np);
                 atomicAdd(stats + 10, (unsigned long long)n_rin); atomicAdd(stats + 11, (unsigned long long)n_rlf);
+#ifdef RT_PHASE_TIMING
+                atomicAdd(stats + 12, ph_gen); atomicAdd(stats + 13, ph_scan); atomicAdd(stats + 14, ph_trav); atomicAdd(stats + 15, ph_shade);
+#endif
             }
         }
     }

@@ -89,7 +89,7 @@ class Scene:
     def renderColumnsDevice(self, d_rgba, d_depth, d_ids=None, d_stats=None, stream=None,
                             x_begin=0, x_end=None, x_step=1):
         """Asynchronous render into DEVICE buffers (raw pointers, e.g. torch `data_ptr()`), on `stream`
-        (a hipStream_t value, e.g. `torch.cuda.current_stream().cuda_stream`).  d_stats: 2 x u64."""
+        (a hipStream_t value, e.g. `torch.cuda.current_stream().cuda_stream`).  d_stats: abi.RT_STATS_WORDS x u64."""
         self.upload()
         p = self.params(x_begin, x_end, x_step)
         abi.check(self._lib, self._lib.rt_render_device(self._scene, C.byref(self.camera), C.byref(p),

@@ -31,7 +31,7 @@ def test_header_compiles_as_c_and_layouts_match_ctypes():
         out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
     got = [int(x) for x in out]
     want = [C.sizeof(abi.rt_surface), C.sizeof(abi.rt_camera), C.sizeof(abi.rt_params), abi.rt_params.seed.offset,
-            abi.rt_params.x_begin.offset, abi.rt_surface.g.offset, abi.rt_params.pool_blocks.offset, abi.RT_ABI_VERSION, 12]
+            abi.rt_params.x_begin.offset, abi.rt_surface.g.offset, abi.rt_params.pool_blocks.offset, abi.RT_ABI_VERSION, 16]
     assert got == want
     assert abi.surface_dtype.itemsize == C.sizeof(abi.rt_surface)
 
