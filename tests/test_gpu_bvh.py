@@ -69,6 +69,19 @@ def test_ties_resolve_to_lowest_index():
     hit = idx >= 0
     assert hit.mean() > 0.5
 
+def test_deep_traversal_stack_spills_to_hbm():
+    """20 000 large spheres that all contain the camera: every box of the tree is hit, the per-lane stack grows to
+    3 x depth = 21 entries, past the 16-entry LDS ring, so the HBM backing store of rt_bvh.h is exercised."""
+    rng = np.random.default_rng(11)
+    n = 20000
+    s = scenes.many_spheres(n, seed=4, environment=False)
+    s["g"][:, :3] = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    s["g"][:, 2] -= np.float32(1.0)
+    s["g"][:, 3] = rng.uniform(6.0, 9.0, n).astype(np.float32)
+    both = np.concatenate([s, scenes.reference_environment(1)])
+    _compare(Scene(surfaces=both, width=40, height=30, samplesPerPixel=1, maxTraceDepth=2, jitter=1, seed=13,
+                   lambertian_samples=2, cameraOriginWS=(0.0, 0.0, 0.0), lookAt=(0.0, 0.0, -1.0)))
+
 
 def test_find_closest_100k_triangle_mesh():
     """config 3's mesh (100352 triangles): random rays, bit-exact t and index against the brute-force scan."""
