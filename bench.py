@@ -245,6 +245,20 @@ def main():
                 continue
             r, t, k, _ = run(wl, st, 1)
             extra[wl] = {"Mrays_per_s": r / t / 1e6, "ms_per_frame": t / st * 1e3, "kernel_ms": k, "rays_per_frame": r / st}
+        # the same frames through rt_render (HOST buffers: staging + PCIe copies of rgba/depth/ids inside the call);
+        # reported beside the device-resident figures, never as `value`
+        hostbuf = {}
+        for wl, st in (("c1", 10), ("c2", 5)):
+            cfg = dict(WORKLOADS[wl])
+            s = Scene(device=local_rank, **cfg)
+            s.renderScene()
+            t0 = time.perf_counter()
+            for _ in range(st):
+                s.renderScene()
+            t = time.perf_counter() - t0
+            hostbuf[wl] = {"Mrays_per_s": s.rayCount * st / t / 1e6, "ms_per_frame": t / st * 1e3}
+            s.close()
+        extra["host_buffers_pcie_inclusive"] = hostbuf
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
