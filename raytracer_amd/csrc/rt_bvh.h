@@ -27,7 +27,7 @@ struct BvhRef {
     int nnodes;
 };
 
-constexpr int kBvhLeafMax = 4;           // primitives per leaf (3 bits in a leaf ref)
+constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a leaf ref)
 constexpr int kBvhStack = 64;             // host guarantees 3 * (tree depth) + 1 <= kBvhStack
 constexpr int kBvhRing = 16;              // entries of the stack kept in LDS by the render kernel
 
