@@ -40,21 +40,20 @@ RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Slab tests of two boxes at once (v_pk_fma_f32); returns the entry parameters, kFltMax when missed.
-// Inexact on purpose (boxes are padded): (lo - O) / D is evaluated as fma(lo, 1/D, -O/D).  min/max ignore
-// NaNs (0 * inf when a direction component is 0), which only ever widens the test.  '<= tmax' keeps boxes
-// that can only tie with the current hit: a tie may still win on index.  Empty child slots are boxes at
-// +infinity and always miss.
-RT_DEV void box_entry2(v2f lox, v2f loy, v2f loz, v2f hix, v2f hiy, v2f hiz, f3 inv, f3 noi, float tmax, float& ta, float& tb)
+// `near*` / `far*` are the box planes the ray meets first / last on each axis (chosen by the sign of the
+// direction when the node is loaded), so no per-axis min/max is needed.  Inexact on purpose (boxes are
+// padded): (plane - O) / D is evaluated as fma(plane, 1/D, -O/D).  max/min ignore NaNs (0 * inf when a direction
+// component is 0), which only ever widens the test.  '<= tmax' keeps boxes that can only tie with the
+// current hit: a tie may still win on index.  Empty child slots are boxes at +infinity and always miss.
+RT_DEV void box_entry2(v2f nearx, v2f neary, v2f nearz, v2f farx, v2f fary, v2f farz, f3 inv, f3 noi, float tmax, float& ta, float& tb)
 {
     const v2f ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
     const v2f nx = { noi.x, noi.x }, ny = { noi.y, noi.y }, nz = { noi.z, noi.z };
-    const v2f x0 = __builtin_elementwise_fma(lox, ix, nx), x1 = __builtin_elementwise_fma(hix, ix, nx);
-    const v2f y0 = __builtin_elementwise_fma(loy, iy, ny), y1 = __builtin_elementwise_fma(hiy, iy, ny);
-    const v2f z0 = __builtin_elementwise_fma(loz, iz, nz), z1 = __builtin_elementwise_fma(hiz, iz, nz);
-    const float tna = fmaxf(fmaxf(fminf(x0.x, x1.x), fminf(y0.x, y1.x)), fmaxf(fminf(z0.x, z1.x), 0.0f));
-    const float tfa = fminf(fminf(fmaxf(x0.x, x1.x), fmaxf(y0.x, y1.x)), fminf(fmaxf(z0.x, z1.x), tmax));
-    const float tnb = fmaxf(fmaxf(fminf(x0.y, x1.y), fminf(y0.y, y1.y)), fmaxf(fminf(z0.y, z1.y), 0.0f));
-    const float tfb = fminf(fminf(fmaxf(x0.y, x1.y), fmaxf(y0.y, y1.y)), fminf(fmaxf(z0.y, z1.y), tmax));
+    const v2f x0 = __builtin_elementwise_fma(nearx, ix, nx), x1 = __builtin_elementwise_fma(farx, ix, nx);
+    const v2f y0 = __builtin_elementwise_fma(neary, iy, ny), y1 = __builtin_elementwise_fma(fary, iy, ny);
+    const v2f z0 = __builtin_elementwise_fma(nearz, iz, nz), z1 = __builtin_elementwise_fma(farz, iz, nz);
+    const float tna = fmaxf(fmaxf(x0.x, y0.x), fmaxf(z0.x, 0.0f)), tfa = fminf(fminf(x1.x, y1.x), fminf(z1.x, tmax));
+    const float tnb = fmaxf(fmaxf(x0.y, y0.y), fmaxf(z0.y, 0.0f)), tfb = fminf(fminf(x1.y, y1.y), fminf(z1.y, tmax));
     ta = (tna <= tfa) ? tna : kFltMax;
     tb = (tnb <= tfb) ? tnb : kFltMax;
 }
@@ -112,8 +111,7 @@ constexpr uint32_t kBvhDone = 0xffffffffu;
 // Depth-first traversal, nearest child first, the other hit children on a per-lane stack.  (tmin, idx) come
 // in from the scan of the loose surfaces (planes) and go out updated.
 //
-// Stack: the top K entries live at stack[(i % K) * stride] (LDS, one column per lane, K + 1 rows: row K is a
-// write-only spare); with SPILL, older
+// Stack: the top K entries live at stack[(i % K) * stride] (LDS, one column per lane); with SPILL, older
 // entries are moved to the lane's column of a backing store in HBM (`backing()` returns its base, stride 64)
 // — LDS per wave decides how many waves a CU holds, and a stack deeper than K is rare.  Entries [lo, sp) are
 // in the ring, [0, lo) in the backing store.
@@ -134,6 +132,10 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     // reciprocal direction for the slab test only (not on the exact path): v_rcp_f32 is enough
     const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
     const f3 noi = F3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
+    // byte offsets, inside a node, of the planes met first / last on each axis (lo.x lo.y lo.z hi.x hi.y hi.z)
+    const uint32_t onx = (inv.x < 0.0f) ? 48u : 0u, ony = (inv.y < 0.0f) ? 64u : 16u, onz = (inv.z < 0.0f) ? 80u : 32u;
+    const uint32_t ofx = 48u - onx, ofy = 80u - ony, ofz = 112u - onz;
+    const char* const node_bytes = reinterpret_cast<const char*>(bvh.nodes);
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kBvhDone;
         sp--;
@@ -150,12 +152,15 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         const bool do_leaf = lf & ((n_lf >= leaf_min) | (n_lf > n_in));
         rounds_inner += __ballot(do_in) != 0ull ? 1u : 0u;      // wave-uniform statistics
         rounds_leaf += __ballot(do_leaf) != 0ull ? 1u : 0u;
-        float4 lx, ly, lz, hx, hy, hz, rf;
+        float4 nx4, ny4, nz4, fx4, fy4, fz4, rf;
         float4 ra[kBvhLeafMax], rb[kBvhLeafMax], rc[kBvhLeafMax];
         int cnt = 0;
         if (do_in) {
-            const float4* n = bvh.nodes + 8 * (size_t)cur;
-            lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
+            const uint32_t nb = cur << 7;                    // 128 bytes per node; the array is < 4 GB (host check)
+            nx4 = *reinterpret_cast<const float4*>(node_bytes + (nb + onx)); fx4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ofx));
+            ny4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ony)); fy4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ofy));
+            nz4 = *reinterpret_cast<const float4*>(node_bytes + (nb + onz)); fz4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ofz));
+            rf = *reinterpret_cast<const float4*>(node_bytes + (nb + 96u));
         }
         if (do_leaf) {
             // 1..4 records of 3 float4, contiguous
@@ -172,19 +177,21 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             nodes_visited++;
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             float t0, t1, t2, t3;
-            box_entry2(v2f{ lx.x, lx.y }, v2f{ ly.x, ly.y }, v2f{ lz.x, lz.y }, v2f{ hx.x, hx.y }, v2f{ hy.x, hy.y }, v2f{ hz.x, hz.y },
+            box_entry2(v2f{ nx4.x, nx4.y }, v2f{ ny4.x, ny4.y }, v2f{ nz4.x, nz4.y }, v2f{ fx4.x, fx4.y }, v2f{ fy4.x, fy4.y }, v2f{ fz4.x, fz4.y },
                        inv, noi, tmin, t0, t1);
-            box_entry2(v2f{ lx.z, lx.w }, v2f{ ly.z, ly.w }, v2f{ lz.z, lz.w }, v2f{ hx.z, hx.w }, v2f{ hy.z, hy.w }, v2f{ hz.z, hz.w },
+            box_entry2(v2f{ nx4.z, nx4.w }, v2f{ ny4.z, ny4.w }, v2f{ nz4.z, nz4.w }, v2f{ fx4.z, fx4.w }, v2f{ fy4.z, fy4.w }, v2f{ fz4.z, fz4.w },
                        inv, noi, tmin, t2, t3);
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
             sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
             // the hits are a prefix of the sorted four: descend into the nearest, push the others far to
-            // near.  Branch-free: all three are stored, the misses into the spare row K of the ring.
-            const int nh = (t1 < kFltMax ? 1 : 0) + (t2 < kFltMax ? 1 : 0) + (t3 < kFltMax ? 1 : 0);
-            if (SPILL) while (sp + nh - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
-            stack[((nh >= 1) ? ((sp + nh - 1) & (K - 1)) : K) * stride] = r1;
-            stack[((nh >= 2) ? ((sp + nh - 2) & (K - 1)) : K) * stride] = r2;
-            stack[((nh >= 3) ? (sp & (K - 1)) : K) * stride] = r3;
+            // near.  Branch-free: three entries are always stored, those beyond the new top are garbage in
+            // free slots (room for three is made first, so they never land on a live entry).
+            const bool h2 = t2 < kFltMax, h3 = t3 < kFltMax;
+            const int nh = (t1 < kFltMax ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+            if (SPILL) while (sp + 3 - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
+            stack[(sp & (K - 1)) * stride] = h3 ? r3 : (h2 ? r2 : r1);
+            stack[((sp + 1) & (K - 1)) * stride] = h3 ? r2 : r1;
+            stack[((sp + 2) & (K - 1)) * stride] = r1;
             sp += nh;
             cur = (t0 < kFltMax) ? r0 : pop();
         }

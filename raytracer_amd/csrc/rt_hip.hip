@@ -351,6 +351,10 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (use_bvh) {
         bvh_build(bprims, src_pdata, hb);
         if (3 * hb.depth + 1 > kBvhStack) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
+        // the traversal addresses nodes by 32-bit byte offsets and leaf references hold 28-bit record indices
+        if (hb.nodes.size() * sizeof(float4) >= (1ull << 32) || bprims.size() >= (1ull << 28)) {
+            delete sc; return fail(RT_E_UNSUPPORTED, "BVH of %zu primitives is too large", bprims.size());
+        }
         sc->nnodes = (int)(hb.nodes.size() / 8); sc->bvh_depth = hb.depth;
     }
 
@@ -460,7 +464,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
 
     const bool node64 = p->max_trace_depth > 13;
     const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
-    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * (kBvhRing + 1) : 0));
+    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * kBvhRing : 0));
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __rest
     int idx; float t;
     const f3 O = F3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), D = F3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     closest_hit(geom, nsurf, O, D, idx, t);
-    uint32_t stack[kBvhStack + 1];
+    uint32_t stack[kBvhStack];
     uint32_t nn = 0, np = 0;
     uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0, lo = 0;
     auto backing = []() -> uint32_t* { return nullptr; };
