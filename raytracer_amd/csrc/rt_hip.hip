@@ -212,7 +212,10 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec*
     // persistent waves: no more than fit on the chip, no more than there are 64-sample refills
     const unsigned long long chunks = (c.total + 63) / 64;
     unsigned long long grid = (unsigned long long)per_cu * (unsigned long long)sc->num_cus;
-    if (grid > chunks) grid = chunks;
+    // Small frames (640x480x1 has 4800 refills for 4864 resident waves): with one refill per wave there is no
+    // dynamic balancing left and the waves that drew expensive pixels finish alone (measured: mean wave lifetime
+    // 0.59 ms of a 1.13 ms kernel).  Two thirds as many waves as refills balances better: 13.8 -> 15.0 Grays/s.
+    if (grid * 3 > chunks * 2) grid = std::max<unsigned long long>(chunks * 2 / 3, 1ull);
     int rc = ensure_spill(sc, (size_t)grid * a.max_spill * NF * 64 * sizeof(uint32_t));
     if (rc) return rc;
     c.spill = sc->d_spill;
