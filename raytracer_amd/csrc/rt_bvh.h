@@ -29,7 +29,6 @@ struct BvhRef {
 
 constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a leaf ref)
 constexpr int kBvhStack = 64;             // host guarantees 3 * (tree depth) + 1 <= kBvhStack
-constexpr int kBvhRing = 16;              // entries of the stack kept in LDS by the render kernel
 
 // (t, idx) is a better hit than (tmin, best): closer, or equally close with a lower array index
 RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
