@@ -472,7 +472,7 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
     // LDS entries of the traversal stacks: see trace_kernel's RING
     const int ring = (sc->nprims <= kBvhSmallTree) ? 8 : 16;
-    const size_t smem = sizeof(uint32_t) * ((size_t)kLdsPool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * ring : 0));
+    const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring)).pool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * ring : 0));
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));

@@ -93,15 +93,21 @@ RT_DEV unsigned long long to_fixed(float x)
     return ((unsigned long long)(uint32_t)hi << 32) | lo;
 }
 
-constexpr int kSlots = 64;          // pixel-samples a wave can have in flight
+// pixel-samples a wave can have in flight: 64, or 32 in the 8-entry-ring BVH variant, whose LDS must fit 16 times
+// into a CU (ray trees widen fast enough to fill the lanes from 32 samples)
+constexpr int slots_of(bool bvh, int ring) { return (bvh && ring == 8) ? 32 : 64; }
 
 // LDS of one wave, in dwords: slot table, lane map, record pool
-constexpr int kLdsAcc = 0;                       // u64 [kSlots*3]  radiance of the pixel-sample, 32.32
-constexpr int kLdsPs = kLdsAcc + kSlots * 6;     // u64 [kSlots]    global pixel-sample index (RNG counter)
-constexpr int kLdsPix = kLdsPs + kSlots * 2;     // u32 [kSlots]    compact pixel index (k*H + py)
-constexpr int kLdsPend = kLdsPix + kSlots;       // u32 [kSlots]    records of this slot in the pool or in flight
-constexpr int kLdsMap = kLdsPend + kSlots;       // u32 [64]        lane map (children / slot allocation)
-constexpr int kLdsPool = kLdsMap + 64;           // records, in blocks of 64
+struct LdsLayout {
+    int acc, ps, pix, pend, map, pool;
+    constexpr explicit LdsLayout(int slots)
+        : acc(0),                    // u64 [slots*3]  radiance of the pixel-sample, 32.32
+          ps(slots * 6),             // u64 [slots]    global pixel-sample index (RNG counter)
+          pix(slots * 8),            // u32 [slots]    compact pixel index (k*H + py)
+          pend(slots * 9),           // u32 [slots]    records of this slot in the pool or in flight
+          map(slots * 10),           // u32 [64]       lane map (children / slot allocation)
+          pool(slots * 10 + 64) {}   // records, in blocks of 64
+};
 
 // NODE64 = keep the ray-tree node index in 64 bits (needed when max_trace_depth > 13).
 // BVH    = large scene: `geom` holds only the loose surfaces (planes), spheres and triangles are reached
@@ -118,12 +124,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     extern __shared__ uint32_t smem[];
     const int lane = threadIdx.x;
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
-    unsigned long long* sl_acc = reinterpret_cast<unsigned long long*>(smem + kLdsAcc);
-    unsigned long long* sl_ps = reinterpret_cast<unsigned long long*>(smem + kLdsPs);
-    uint32_t* sl_pix = smem + kLdsPix;
-    uint32_t* sl_pend = smem + kLdsPend;
-    uint32_t* map = smem + kLdsMap;
-    uint32_t* pool = smem + kLdsPool;
+    constexpr int SLOTS = slots_of(BVH, RING);
+    constexpr LdsLayout L(SLOTS);
+    unsigned long long* sl_acc = reinterpret_cast<unsigned long long*>(smem + L.acc);
+    unsigned long long* sl_ps = reinterpret_cast<unsigned long long*>(smem + L.ps);
+    uint32_t* sl_pix = smem + L.pix;
+    uint32_t* sl_pend = smem + L.pend;
+    uint32_t* map = smem + L.map;
+    uint32_t* pool = smem + L.pool;
     // Record r lives in block r/64: field f of record r is the dword pool[(r/64)*NF*64 + f*64 + r%64], so a
     // field is an immediate offset (f*256 bytes) from the record's base address and lanes reading
     // consecutive records hit consecutive banks.
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     const unsigned long long t_start = __builtin_readcyclecounter();
 
     int top = 0;                                // records in the pool (wave-uniform)
-    unsigned long long freemask = ~0ull;        // free slots (wave-uniform)
+    unsigned long long freemask = SLOTS == 64 ? ~0ull : ((1ull << SLOTS) - 1ull);   // free slots (wave-uniform)
     unsigned long long res_next = 0;            // first pixel-sample of the current refill
     bool exhausted = false;                     // the global counter has run past the end
     uint32_t nrays = 0;                         // closest-hit queries by this lane
