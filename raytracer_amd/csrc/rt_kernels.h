@@ -424,7 +424,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         RT_PHASE(ph_scan)
         if (BVH) {
             // new and suspended rays walk the tree together; leave early only when other work can fill the lanes
-            const bool refill = top > 0 || nspill > 0 || !exhausted;
+            // (an iteration that could not start a single new ray — no free slot, nothing poppable — must not
+            // leave early either, or the wave would spin without progress)
+            const bool refill = (nchild + nprim > 0) && (top > 0 || nspill > 0 || !exhausted);
             if (!alive) trav_cur = kBvhDone;
             auto backing = [&]() { return cold_args()->gstack + (size_t)blockIdx.x * (kBvhStack * 64) + lane; };
             closest_hit_bvh<RING, true>(bvh, O, Dn, bvh_stack, 64, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
