@@ -446,8 +446,9 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
-    // half of its lanes still walk the tree; a group of lanes steps once 16 of them have gathered
-    a.min_active = 32;
+    // 28 of its lanes still walk the tree (must not exceed the 32 sample slots of the small-tree variant, see
+    // trace_kernel); a group of lanes steps once 16 of them have gathered
+    a.min_active = 28;
     a.leaf_min = 16;
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
