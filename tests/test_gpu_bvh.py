@@ -130,3 +130,39 @@ def test_c3_mesh_frame_properties():
         assert np.array_equal(rgba, full[r::2]) and np.array_equal(ids, s.objectIds[r::2])
         tot += n
     assert tot == rays
+
+
+def test_bvh_column_partition_and_determinism():
+    """The multi-GPU partition on a BVH scene: interleaved column sets equal the full frame bit for bit, and a
+    second render of the same frame is identical (suspended rays, lane refill and stack spills change the order in
+    which rays are traced, never the sums)."""
+    m = np.concatenate([_records(SD.scene_spheres), scenes.heightfield_mesh(24, environment=False, base=-5.9, amplitude=1.0)])
+    s = Scene(surfaces=m, width=120, height=90, samplesPerPixel=4, maxTraceDepth=4, jitter=1, seed=21)
+    s.renderScene()
+    full, depth, ids, rays = s.frameBuffer.copy(), s.depthBuffer.copy(), s.objectIds.copy(), s.rayCount
+    s.renderScene()
+    assert np.array_equal(full, s.frameBuffer) and s.rayCount == rays
+    total = 0
+    for r in range(3):
+        rgba, d, i, _, n = s.renderColumns(r, s.width, 3)
+        assert np.array_equal(rgba, full[r::3]) and np.array_equal(d, depth[r::3]) and np.array_equal(i, ids[r::3])
+        total += n
+    assert total == rays
+
+
+def test_invalid_surfaces_are_rejected_with_a_message():
+    """Error behaviour of the boundary: bad input is RT_E_INVALID with text, never a crash or a silent render."""
+    good = _records(SD.scene_spheres)
+
+    def expect_invalid(mutate, needle):
+        bad = good.copy()
+        mutate(bad)
+        with pytest.raises(abi.RtError) as e:
+            Scene(surfaces=bad, width=8, height=8).renderScene()
+        assert e.value.code == abi.RT_E_INVALID and needle in str(e.value)
+
+    expect_invalid(lambda a: a["geom"].__setitem__(3, 7), "bad geometry")
+    expect_invalid(lambda a: a["kind"].__setitem__(0, 9), "bad kind")
+    expect_invalid(lambda a: a["sample_count"].__setitem__(1, 5), "sample_count")
+    rect = int(np.flatnonzero((good["geom"] == abi.GEOM_PLANE) & (good["g"][:, 4] != 0))[0])
+    expect_invalid(lambda a: a["g"].__setitem__((rect, 8), -1.0), "negative rectangle")
