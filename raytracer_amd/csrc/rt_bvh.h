@@ -10,8 +10,9 @@
 // (measured with a binary tree of 32-byte nodes: 28 visits per ray, ~1.6 TB/s of 64-byte random reads,
 // 0.65 Grays/s on the 100k-triangle mesh), so a node holds FOUR child boxes in exactly one 128-byte line:
 //   nodes[]   8 float4 per node: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] ref[4] pad
-//             ref: 0 = empty slot (its box lies at +infinity and is never hit); bit 31 set = leaf, (ref & 0x7fffffff) >> 3 = first primitive slot,
-//             ref & 7 = primitive count (1..4); otherwise the index of an inner node (never 0 = root)
+//             ref: 0 = empty slot (its box lies at +infinity and is never hit); bit 31 set = leaf,
+//             (ref & 0x7fffffff) >> 3 = first primitive slot, ref & 7 = primitive count (1..kBvhLeafMax);
+//             otherwise the index of an inner node (never 0 = root)
 //   pdata[]   3 float4 per primitive slot, in BVH order so a leaf's records are contiguous:
 //             sphere   = (centre, r^2) (0,0,0,0)       (0,    surface index, 0, 0)
 //             triangle = (v0, e1.x)    (e1.yz, e2.xy)  (e2.z, surface index, 1, 0)
@@ -115,10 +116,10 @@ constexpr uint32_t kBvhDone = 0xffffffffu;
 // — LDS per wave decides how many waves a CU holds, and a stack deeper than K is rare.  Entries [lo, sp) are
 // in the ring, [0, lo) in the backing store.
 //
-// Shape of the loop: every round, the lanes at an inner node take one step; the lanes at a leaf wait until
-// at least `leaf_min` of them have gathered (or no lane is at an inner node), then test their leaves together:
-// a leaf costs ~3 inner steps of VALU work, too much to run for a handful of lanes.  The loads of both groups
-// are issued before either is used, so a round costs one memory latency.
+// Shape of the loop: every round, each of the two groups of lanes — those at an inner node, those at a leaf —
+// takes one step if at least `leaf_min` lanes have gathered in it, the larger group in any case: the two
+// steps are different code, too much to run for a handful of lanes.  The loads of both groups are issued
+// before either is used, so a round costs one memory latency.
 //
 // `cur`/`sp`/`lo` are the lane's traversal state: cur = kBvhDone: no ray, 0: at the root.  The call returns
 // when no lane is walking or fewer than `min_active` are; those continue in the next call.
