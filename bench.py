@@ -70,8 +70,9 @@ VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (packed FM
 
 
 # BVH scenes: 20 flops per box test (four per visit of a 4-wide node), 40 per triangle test, 27
-# per sphere test, plus the loose planes scanned per ray; bytes: 128 per node visit, 48 per primitive record.
-BVH_COST = {"c3": dict(scan=19.0 + 2 * 44.0, prim=40.0), "c4": dict(scan=19.0 + 5 * 44.0, prim=40.0),
+# per sphere test, plus the surfaces scanned per ray (planes; in c4 also the 6 spheres of scene_spheres, which a mesh
+# scene keeps out of the tree); bytes: 128 per node visit, 48 per primitive record.
+BVH_COST = {"c3": dict(scan=19.0 + 2 * 44.0, prim=40.0), "c4": dict(scan=FLOPS_SCAN, prim=40.0),
             "c5": dict(scan=19.0 + 2 * 44.0, prim=27.0)}
 
 

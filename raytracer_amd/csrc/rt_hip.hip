@@ -234,6 +234,7 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec*
 
 // A scene goes through the BVH when it has triangles or more spheres than a wave-uniform scan should test.
 constexpr int64_t kBvhThreshold = 64;
+constexpr int64_t kLooseSpheres = 16;
 // Up to this many primitives the 8-entry stack ring is used (measured: 100k triangles +2..10 %, 1M spheres -11 %).
 constexpr int64_t kBvhSmallTree = 262144;
 
@@ -257,11 +258,15 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
 
     std::vector<GeomRec> geom;
     geom.reserve((size_t)std::min<int64_t>(n, 4096));
-    int64_t nprim = 0; bool any_tri = false;
+    int64_t nprim = 0, nsphere = 0; bool any_tri = false;
     for (int64_t i = 0; i < n; i++) {
         if (surfaces[i].geom == RT_GEOM_SPHERE || surfaces[i].geom == RT_GEOM_TRIANGLE) nprim++;
+        if (surfaces[i].geom == RT_GEOM_SPHERE) nsphere++;
         if (surfaces[i].geom == RT_GEOM_TRIANGLE) any_tri = true;
     }
+    // A handful of spheres in a mesh scene stay in the scanned list: in the tree each of them is a second kind of
+    // leaf step that most rounds would have to run (measured on the 4K mixed scene).
+    const bool loose_spheres = any_tri && nsphere <= kLooseSpheres;
     const bool use_bvh = any_tri || n > kBvhThreshold;
     std::vector<BuildPrim> bprims;
     HostBvh hb;
@@ -287,7 +292,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             g.a[0] = s.g[0]; g.a[1] = s.g[1]; g.a[2] = s.g[2];
             g.a[3] = s.g[3] * s.g[3];                                                   // Square radius, Sphere.fs:21
             h.nc[0] = s.g[0]; h.nc[1] = s.g[1]; h.nc[2] = s.g[2];
-            if (use_bvh) {
+            if (use_bvh && !loose_spheres) {
                 BuildPrim bp;
                 const float r = std::fabs(s.g[3]);
                 for (int k = 0; k < 3; k++) { bp.lo[k] = s.g[k] - r; bp.hi[k] = s.g[k] + r; bp.c[k] = s.g[k]; }
@@ -349,7 +354,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
         if (s.kind == RT_KIND_LAMBERTIAN && s.sample_count == 0) sc->lamb_default.push_back((int)i);
         h.info = (uint32_t)s.kind | ((uint32_t)ns << 2) | ((uint32_t)gtype << 5);
         // the scalar-operand linear list: every surface of a small scene, only the planes of a BVH scene
-        if (!use_bvh || s.geom == RT_GEOM_PLANE) geom.push_back(g);
+        if (!use_bvh || s.geom == RT_GEOM_PLANE || (s.geom == RT_GEOM_SPHERE && loose_spheres)) geom.push_back(g);
         sc->h_shade[(size_t)i] = h;
     }
     sc->nloose = (int64_t)geom.size();
