@@ -136,6 +136,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     const uint32_t onx = (inv.x < 0.0f) ? 48u : 0u, ony = (inv.y < 0.0f) ? 64u : 16u, onz = (inv.z < 0.0f) ? 80u : 32u;
     const uint32_t ofx = 48u - onx, ofy = 80u - ony, ofz = 112u - onz;
     const char* const node_bytes = reinterpret_cast<const char*>(bvh.nodes);
+    const char* const pdata_bytes = reinterpret_cast<const char*>(bvh.pdata);
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kBvhDone;
         sp--;
@@ -168,7 +169,9 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             cnt = (int)(cur & 7u);
 #pragma unroll
             for (int k = 0; k < kBvhLeafMax; k++) {
-                const float4* p = bvh.pdata + 3 * (size_t)(first + ((k < cnt) ? k : cnt - 1));
+                // 48-byte records addressed by 32-bit byte offsets from the uniform base (the array is < 4 GB)
+                const uint32_t off = (uint32_t)(first + ((k < cnt) ? k : cnt - 1)) * 48u;
+                const float4* p = reinterpret_cast<const float4*>(pdata_bytes + off);
                 ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
             }
         }

@@ -362,8 +362,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (use_bvh) {
         bvh_build(bprims, src_pdata, hb);
         if (3 * hb.depth + 1 > kBvhStack) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
-        // the traversal addresses nodes by 32-bit byte offsets and leaf references hold 28-bit record indices
-        if (hb.nodes.size() * sizeof(float4) >= (1ull << 32) || bprims.size() >= (1ull << 28)) {
+        // the traversal addresses nodes and records by 32-bit byte offsets and leaf references hold 28-bit record indices
+        if (hb.nodes.size() * sizeof(float4) >= (1ull << 32) || hb.pdata.size() * sizeof(float4) >= (1ull << 32) || bprims.size() >= (1ull << 28)) {
             delete sc; return fail(RT_E_UNSUPPORTED, "BVH of %zu primitives is too large", bprims.size());
         }
         sc->nnodes = (int)(hb.nodes.size() / 8); sc->bvh_depth = hb.depth; sc->nprims = (int64_t)bprims.size();
