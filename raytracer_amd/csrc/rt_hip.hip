@@ -462,7 +462,9 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, voi
     a.nblk = p->pool_blocks > 0 ? p->pool_blocks : 2;   // measured: 2 blocks (19 waves/CU) beats 3, 4, 6
     if (a.nblk > levels) a.nblk = levels;
     if (a.nblk < 2 && levels >= 2) a.nblk = 2;
-    a.max_spill = levels;
+    // (a BVH scene gets twice the proven capacity: its rays finish out of order, so records of one level can be
+    // pushed while a few suspended rays of the level above are still walking)
+    a.max_spill = sc->use_bvh ? 2 * levels : levels;
 
     // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
     const float* M = cam->cam_to_world;
