@@ -166,3 +166,23 @@ def test_invalid_surfaces_are_rejected_with_a_message():
     expect_invalid(lambda a: a["sample_count"].__setitem__(1, 5), "sample_count")
     rect = int(np.flatnonzero((good["geom"] == abi.GEOM_PLANE) & (good["g"][:, 4] != 0))[0])
     expect_invalid(lambda a: a["g"].__setitem__((rect, 8), -1.0), "negative rectangle")
+
+
+def test_bvh_deep_branching_stays_within_the_pool_bound():
+    """Seven bounces of 4-way branching in the mixed scene: up to 21 845 rays per pixel-sample, records of eight levels in
+    the pool, rays finishing out of order.  The pool must not overflow (rt_scene_status) and the frame must not
+    depend on the order: two renders and a 2-way column partition agree bit for bit."""
+    m = np.concatenate([_records(SD.scene_spheres), scenes.heightfield_mesh(8, environment=False, base=-5.9, amplitude=1.0)])
+    s = Scene(surfaces=m, width=40, height=30, samplesPerPixel=1, maxTraceDepth=7, jitter=1, seed=17)
+    s.renderScene()
+    s.status()
+    full, rays = s.frameBuffer.copy(), s.rayCount
+    assert rays > 40 * 30 * 200
+    s.renderScene()
+    assert np.array_equal(full, s.frameBuffer) and s.rayCount == rays
+    total = 0
+    for r in range(2):
+        rgba, _, _, _, n = s.renderColumns(r, s.width, 2)
+        assert np.array_equal(rgba, full[r::2])
+        total += n
+    assert total == rays
