@@ -215,3 +215,33 @@ def test_c4_4k_64spp_frame_properties():
     # emitters seen directly are exactly white after gamma
     lights = np.isin(s.objectIds, [1, 2])
     assert lights.any() and np.all(s.frameBuffer[lights][:, :3] == 1.0)
+
+
+def test_rccl_collectives_of_the_frame_gather():
+    """The collectives FrameGatherer issues for N > 1 (gather of the packed f32 block, f64 all-reduces), run on RCCL
+    with a one-rank group: the multi-GPU bench itself only runs on the driver's 8-GPU node."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import multi
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=dev)
+    try:
+        s = Scene(width=64, height=48, samplesPerPixel=1, maxTraceDepth=3, jitter=0)
+        s.renderScene()
+        g = multi.FrameGatherer(s.width, s.height, dev, rank=0, world=1)
+        rgba = torch.from_numpy(s.frameBuffer).to(dev)
+        depth = torch.from_numpy(s.depthBuffer).to(dev)
+        g.part[:, :, 0:4] = rgba
+        g.part[:, :, 4] = depth
+        dist.gather(g.part, g.recv, dst=0)
+        st = torch.tensor([float(s.rayCount)], dtype=torch.float64, device=dev)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        mx = torch.tensor([float(s.maxFrameBufferDepth)], dtype=torch.float64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        assert torch.equal(g.recv[0][:, :, 0:4], rgba) and int(st.item()) == s.rayCount
+        assert float(mx.item()) == float(np.float32(s.maxFrameBufferDepth))
+    finally:
+        dist.destroy_process_group()
