@@ -220,3 +220,23 @@ def test_depth_accounting_matches_the_recursion():
         assert prev <= r["rays"] <= 16 * 12 * sum(4 ** k for k in range(d + 2))
         prev = r["rays"]
     assert prev > 16 * 12 * 5
+
+
+def test_triangle_known_answers():
+    """The build's own triangle Hitable (no reference counterpart; include/rt_abi.h RT_GEOM_TRIANGLE): Moeller-Trumbore
+    with fused multiply-adds.  Hand-derived answers on the unit right triangle in the plane z = -2."""
+    tri = host.Lambertian(7, host.Triangle((0.0, 0.0, -2.0), (1.0, 0.0, -2.0), (0.0, 1.0, -2.0)), host.Material(host.Rgba32.Red))
+    down = (0.0, 0.0, -1.0)
+    has, t, acc = O.intersect(tri, (0.25, 0.25, 0.0), down)          # interior: t = 2 exactly
+    assert has and acc and t == 2.0
+    has, t, acc = O.intersect(tri, (0.25, 0.25, -4.0), (0.0, 0.0, 1.0))   # from behind: no back-face culling
+    assert has and acc and t == 2.0
+    assert O.intersect(tri, (0.5, 0.5, 0.0), down)[0]               # on the hypotenuse, u + v = 1: inside (<=)
+    assert O.intersect(tri, (0.0, 0.0, 0.0), down)[0]               # on the vertex v0, u = v = 0: inside (>=)
+    assert not O.intersect(tri, (0.51, 0.5, 0.0), down)[0]          # just outside the hypotenuse
+    assert not O.intersect(tri, (-0.01, 0.5, 0.0), down)[0]         # u < 0
+    assert not O.intersect(tri, (0.25, 0.25, 0.0), (1.0, 0.0, 0.0))[0]   # parallel to the plane: |det| < 1e-12
+    has, t, acc = O.intersect(tri, (0.25, 0.25, -2.0005), (0.0, 0.0, 1.0))   # hit closer than TMin = 0.001
+    assert has and not acc and abs(t - 0.0005) < 1e-6
+    has, t, acc = O.intersect(tri, (0.25, 0.25, 0.0), (0.0, 0.0, 1.0))   # pointing away: t = -2, not acceptable
+    assert has and not acc and t == -2.0
