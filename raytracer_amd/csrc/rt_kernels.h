@@ -93,9 +93,10 @@ RT_DEV unsigned long long to_fixed(float x)
     return ((unsigned long long)(uint32_t)hi << 32) | lo;
 }
 
-// pixel-samples a wave can have in flight: 64, or 32 in the 8-entry-ring BVH variant, whose LDS must fit 16 times
-// into a CU (ray trees widen fast enough to fill the lanes from 32 samples)
-constexpr int slots_of(bool bvh, int ring) { return (bvh && ring == 8) ? 32 : 64; }
+// pixel-samples a wave can have in flight: 32 (ray trees widen fast enough to fill the lanes from 32 samples, and
+// the smaller slot table buys waves: linear-scan kernel 8.4 -> 7.2 KB of LDS, 19 -> 22 waves/CU, c4s +6 %; small-
+// tree BVH kernel 16 waves/CU; 16 slots were measured 30-45 % slower); 64 in the large-tree BVH variant
+constexpr int slots_of(bool bvh, int ring) { return (!bvh || ring == 8) ? 32 : 64; }
 
 // LDS of one wave, in dwords: slot table, lane map, record pool
 struct LdsLayout {
