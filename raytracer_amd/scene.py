@@ -114,16 +114,21 @@ class Scene:
     # -- Scene.fs:123-144 (PNG instead of JPEG: lossless, no ImageSharp) -------------------------
     @staticmethod
     def _to_rgba32(v):
-        """Rgba32(Vector4): clamp to [0,1], scale by 255, round half away from zero."""
-        return np.floor(np.clip(v, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+        """ImageSharp `Rgba32(Vector4)` (Scene.fs:128,140): v*255 + 0.5, clamped to [0,255], truncated to a byte."""
+        with np.errstate(over="ignore", invalid="ignore"):
+            s = np.asarray(v, dtype=np.float32) * np.float32(255.0) + np.float32(0.5)
+        s = np.where(np.isnan(s), np.float32(0.0), s)
+        return np.clip(s, 0.0, 255.0).astype(np.uint8)
 
     def frameBufferImage(self):
-        return self._to_rgba32(self.frameBuffer).transpose(1, 0, 2)          # image.Item(px,py): x = column
+        """[H, W, 4] u8: the image saveFrameBuffer hands to the encoder (image.Item(px,py) <- Rgba32 frameBuffer[px,py])."""
+        return self._to_rgba32(self.frameBuffer).transpose(1, 0, 2)
 
     def depthBufferImage(self):
+        """[H, W, 4] u8: Vector4(Vector3(depth / maxFrameBufferDepth), 1) per pixel (Scene.fs:139); a miss holds
+        Single.MaxValue and saturates to white."""
         with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-            g = self.depthBuffer / np.float32(self.maxFrameBufferDepth)       # Scene.fs:139
-        g = np.nan_to_num(g, nan=1.0, posinf=1.0)
+            g = self.depthBuffer / np.float32(self.maxFrameBufferDepth)
         rgba = np.stack([g, g, g, np.ones_like(g)], axis=-1)
         return self._to_rgba32(rgba).transpose(1, 0, 2)
 

@@ -5,12 +5,18 @@
   oracle_c2_48x36.npz      oracle render: scene_spheres, 48x36, 4 spp, maxTraceDepth 4, jitter, seed 7
   oracle_ref_40x30_hi.npz  oracle render: 40x30, 32768 spp, maxTraceDepth 4, pinhole, seed 1001 (the high-spp
                            reference of the PSNR check; ~1.5 minutes on 8 cores)
-  display_100x80.npy       the reference's own render display.jpg (800x640) box-filtered 8x8 to 100x80 RGB
-                           u8 -- DATA from /root/reference (a soft visual fixture)
+  ref_depth_800x640.npz    DATA from /root/reference/depth.jpg (written by Scene.saveDepthBuffer, Scene.fs:134-144):
+                           the full-resolution 8-bit luminance of the decoded JPEG, [640, 800] u8
+  ref_<name>_100x80.npy    DATA from the reference's own colour renders (Scene.saveFrameBuffer, Scene.fs:123-132)
+                           display.jpg, 16_4_sphere.jpg, 16_6_sphere.jpg, 4_6_sphere.jpg (names read {spp}_{depth}):
+                           the decoded 800x640 RGB, box-filtered 8x8 to [80, 100, 3] f32 in 0..255
 
 The first three pin the oracle against accidental change (they are produced BY the oracle: the
 reference cannot be run here, see DESIGN.md "Oracle"); GPU tests compare the HIP path with them too,
-so the GPU box needs neither /root/reference nor a long CPU render.
+so the GPU box needs neither /root/reference nor a long CPU render.  The ref_* files are pixel data decoded
+from the JPEGs the reference's authors rendered with the reference itself and checked in: they are the only
+reference-produced outputs that exist, and tests/test_golden.py + tests/test_gpu_reference_images.py hold the
+oracle and the HIP path to them (PSNR and miss-mask thresholds stated there).
 """
 import os
 import sys
@@ -38,12 +44,16 @@ def main(which):
     if "hi" in which:
         r = O.render(sc, cam, host.make_params(40, 30, 32768, 4, jitter=0, seed=1001))
         np.savez_compressed(os.path.join(HERE, "oracle_ref_40x30_hi.npz"), rgba=r["rgba"], rays=np.uint64(r["rays"]))
-    if "display" in which:
+    if "reference" in which:
         from PIL import Image
-        im = np.asarray(Image.open("/root/reference/display.jpg").convert("RGB"), dtype=np.float64)   # [640, 800, 3]
-        small = im.reshape(80, 8, 100, 8, 3).mean(axis=(1, 3))
-        np.save(os.path.join(HERE, "display_100x80.npy"), np.round(small).astype(np.uint8))
+        ref = "/root/reference"
+        lum = np.asarray(Image.open(os.path.join(ref, "depth.jpg")).convert("L"), dtype=np.uint8)          # [640, 800]
+        np.savez_compressed(os.path.join(HERE, "ref_depth_800x640.npz"), luminance=lum)
+        for name in ("display", "16_4_sphere", "16_6_sphere", "4_6_sphere"):
+            im = np.asarray(Image.open(os.path.join(ref, name + ".jpg")).convert("RGB"), dtype=np.float64)   # [640, 800, 3]
+            small = im.reshape(80, 8, 100, 8, 3).mean(axis=(1, 3))
+            np.save(os.path.join(HERE, "ref_%s_100x80.npy" % name), small.astype(np.float32))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["c1", "c2", "hi", "display"])
+    main(sys.argv[1:] or ["c1", "c2", "hi", "reference"])
