@@ -38,6 +38,8 @@ extern "C" {
 #define RT_E_HIP          -3   /* a HIP runtime call failed (message has the HIP error)      */
 #define RT_E_OVERFLOW     -4   /* a wave's LDS record pool overflowed its proven bound (a bug) */
 #define RT_E_UNSUPPORTED  -5   /* valid request this build does not implement                */
+#define RT_E_RANGE        -6   /* a radiance contribution was NaN, infinite or >= 2^31 in magnitude
+                                  (the pixel sums are 32.32 fixed point); it was dropped, the image is invalid */
 
 /* ---- surface kinds: the Surface subclasses of raytracer/Surface.fs ---------------------- */
 #define RT_KIND_NOSURFACE  0   /* Surface.fs:44-47   0 samples, radiance = Emitted           */
@@ -105,7 +107,22 @@ typedef struct rt_params {
     int32_t  x_begin, x_end, x_step;
     int32_t  waves_per_cu;        /* tuning: cap on resident persistent waves per CU; 0 = all that fit */
     int32_t  pool_blocks;         /* tuning: 64-record pool blocks kept in LDS per wave (rest spills to HBM); 0 = auto */
+    int32_t  estimator;           /* RT_ESTIMATOR_BRANCHING (0, the reference's renderScene) or RT_ESTIMATOR_SINGLE_PATH */
+    int32_t  bvh_ring;            /* tuning/testing: traversal-stack entries kept in LDS, 0 = by tree size, 8 or 16
+                                     (selects the kernel variant a BVH scene runs; results do not depend on it)   */
+    int32_t  bvh_min_active;      /* tuning/testing: lanes still walking below which a wave refills; 0 = 28, 1..64 */
+    int32_t  reserved;            /* must be 0                                                                    */
 } rt_params;
+
+/* Estimators.  BRANCHING is what Scene.rayTrace computes (Scene.fs:51-72): every hit spawns SampleCount children
+ * (Lambertian 4, Metal 1, Dielectric the deterministic 1-or-2 split of its GenerateSamples override,
+ * Surface.fs:168-181).  SINGLE_PATH is SURVEY.md 8(f4): one child per hit for every kind — Lambertian and Metal
+ * with SampleCount 1 through the default GenerateSamples (Surface.fs:37-41), Dielectric through its stochastic
+ * `Scatter` (Surface.fs:155-166: reflect when RandomFloat <= reflectProb, else refract; shading = BRDF*(1/PDF) =
+ * Albedo), i.e. the accumulator form of raytracer/notes.txt:21-54 with one ray per level.  Same expectation,
+ * more variance per sample, cost linear in max_trace_depth (what makes 16 bounces tractable).                  */
+#define RT_ESTIMATOR_BRANCHING   0
+#define RT_ESTIMATOR_SINGLE_PATH 1
 
 typedef struct rt_scene rt_scene;   /* opaque: device-resident SoA scene + workspace          */
 
@@ -139,14 +156,25 @@ int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* pa
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);
 
+/* `Scene.renderScene ()` (Scene.fs:117-121) on several GPUs of one node from ONE host thread:
+ * scenes[i] (the same surfaces uploaded to any device, normally device i) renders the interleaved columns
+ * i, i+n, ... of the whole frame on its own stream; each device then stores its block into the frame held in
+ * the HBM of scenes[0]'s device (peer stores over xGMI), which is copied to the host buffers once.
+ * max_depth is the maximum and ray_count the sum over the shares (Scene.fs:47-48).  Output layout and meaning as
+ * rt_render; params->x_begin/x_end/x_step must describe the whole frame (0, width, 1).  With n = 1 the result is
+ * rt_render's bit for bit; for any n the frame is identical (integer radiance sums).                             */
+int  rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* cam, const rt_params* params,
+                     float* rgba, float* depth, uint64_t* object_id, float* max_depth, uint64_t* ray_count);
+
 /* findClosestIntersection (Surface.fs:49-58) as a batch query over host arrays: for ray i with
  * origin origins[3i..] and (unit) direction directions[3i..], index[i] = array index of the
  * closest acceptable surface (-1 = none) and t[i] = its ray parameter (FLT_MAX if none).      */
 int  rt_find_closest(rt_scene* scene, int64_t nrays, const float* origins, const float* directions,
                      float* t, int32_t* index);
 
-/* After a render on `scene` has completed: 0, or RT_E_OVERFLOW if any wave's ray pool
- * overflowed (results are then invalid).  rt_render checks this itself.                       */
+/* After a render on `scene` has completed: 0, RT_E_OVERFLOW if any wave's ray pool overflowed or RT_E_RANGE if a
+ * radiance contribution did not fit the fixed-point sums (results are then invalid).  rt_render and rt_render_multi
+ * check this themselves (and render a BVH scene again with a larger spill area on RT_E_OVERFLOW).               */
 int  rt_scene_status(rt_scene* scene);
 
 void rt_scene_destroy(rt_scene* scene);
@@ -156,7 +184,7 @@ const char* rt_last_error(void);
 
 /* ABI version: bumped whenever a struct layout or signature changes.                         */
 int  rt_abi_version(void);
-#define RT_ABI_VERSION 5
+#define RT_ABI_VERSION 6
 
 #ifdef __cplusplus
 }

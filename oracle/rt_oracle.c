@@ -386,6 +386,7 @@ typedef struct {
     int max_trace_depth;
     v3 background;
     unsigned flags;
+    int estimator;       /* RT_ESTIMATOR_*: 0 = the reference's branching renderScene, 1 = single path */
     uint64_t rays;
 } octx;
 
@@ -487,11 +488,61 @@ static int dielectric_samples(const osurf *s, const ray_t *in, float t, sample_t
     return 2;
 }
 
+/* RandomSampling.RandomFloat_Sync (call site Surface.fs:157): uniform in [0,1); the third word of the Philox
+ * block keyed by (pixel-sample, child node) -- the block whose first two words a hemisphere draw would use. */
+float rto_random_float(uint64_t seed, uint64_t ps, uint64_t node)
+{
+    uint32_t ctr[4] = { (uint32_t)ps, (uint32_t)(ps >> 32), (uint32_t)node, (uint32_t)(node >> 32) };
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t w[4];
+    rto_philox4x32_10(ctr, key, w);
+    return u01(w[2]);
+}
+/* Dielectric.Scatter (Surface.fs:155-166) through the default GenerateSamples (Surface.fs:37-41) with
+ * SampleCount 1: the stochastic pick the reference defines but never reaches (its GenerateSamples override
+ * shadows it).  shading = ComputeSample = BRDF * (cos / PDF) = Albedo * (1 / 1)  (Surface.fs:28,35-36,162,166). */
+static sample_t dielectric_scatter(const octx *c, const osurf *s, const ray_t *in, float t,
+                                   uint64_t ps, uint64_t child_node)
+{
+    v3 p = v3_add(in->o, v3_scale(in->d, t));
+    v3 normal = v3_normalize(geom_normal(s, p));
+    v3 refl = v3_normalize(reflect(in->d, normal));
+    float eta_i, eta_t; v3 fn;
+    if (v3_dot(in->d, normal) > 0.0f) { eta_i = s->ior; eta_t = 1.0f; fn = v3_neg(normal); }
+    else { eta_i = 1.0f; eta_t = s->ior; fn = normal; }
+    float cos_i = v3_dot(in->d, v3_neg(fn));
+    float eta = eta_i / eta_t;
+    float disc = 1.0f - square(eta) * (1.0f - square(cos_i));
+    int refracted = 0; v3 refr = V3(0.0f, 0.0f, 0.0f);
+    if (disc > 0.0f) {
+        v3 q = v3_sub(v3_scale(v3_add(in->d, v3_scale(fn, cos_i)), eta), v3_scale(fn, sqrtf(disc)));
+        refr = v3_normalize(q);
+        refracted = 1;
+    }
+    float reflect_prob = refracted ? schlick(cos_i, eta_i, eta_t) : 1.0f;
+    float random_float = rto_random_float(c->seed, ps, child_node);
+    sample_t r;
+    if (random_float <= reflect_prob) r.ray = make_ray(p, refl);
+    else r.ray = make_ray(p, refr);          /* "refraction has to have been successful" (Surface.fs:163) */
+    r.shading = v3_scale(s->albedo, 1.0f / 1.0f);
+    return r;
+}
+
 /* Surface.GenerateSamples: Surface.fs:37-41 (default), :47 (NoSurface), :168-181 (Dielectric).
  * Child i of tree node `node` is node 4*node+i+1; its hemisphere draw is keyed by that id. */
 static int generate_samples(const octx *c, const osurf *s, const ray_t *in, float t,
                             uint64_t ps, uint64_t node, sample_t out[4])
 {
+    if (c->estimator == RT_ESTIMATOR_SINGLE_PATH) {
+        /* one child per hit, through the default GenerateSamples with SampleCount 1 (notes.txt:21-54 with one
+           ray per level); Dielectric through its stochastic Scatter */
+        switch (s->kind) {
+        case RT_KIND_LAMBERTIAN: out[0] = lambertian_sample(c, s, in, t, ps, 4 * node + 1); return 1;
+        case RT_KIND_METAL:      out[0] = metal_sample(c, s, in, t, ps, 4 * node + 1); return 1;
+        case RT_KIND_DIELECTRIC: out[0] = dielectric_scatter(c, s, in, t, ps, 4 * node + 1); return 1;
+        default:                 return 0;
+        }
+    }
     switch (s->kind) {
     case RT_KIND_LAMBERTIAN:
         for (int i = 0; i < s->nsamples; i++) out[i] = lambertian_sample(c, s, in, t, ps, 4 * node + i + 1);
@@ -574,6 +625,7 @@ static int check_args(const rt_surface *surf, int64_t n, const rt_camera *cam, c
     if (p->max_trace_depth < 0 || p->max_trace_depth > 28) return RT_E_INVALID;
     if (p->lambertian_samples < 0 || p->lambertian_samples > 4) return RT_E_INVALID;
     if (p->x_step <= 0 || p->x_begin < 0 || p->x_end > p->width || p->x_begin > p->x_end) return RT_E_INVALID;
+    if (p->estimator != RT_ESTIMATOR_BRANCHING && p->estimator != RT_ESTIMATOR_SINGLE_PATH) return RT_E_INVALID;
     for (int64_t i = 0; i < n; i++) {
         if (surf[i].kind < 0 || surf[i].kind > 3 || surf[i].geom < 0 || surf[i].geom > 2) return RT_E_INVALID;
         if (surf[i].sample_count < 0 || surf[i].sample_count > 4) return RT_E_INVALID;
@@ -622,7 +674,7 @@ int rto_render(const rt_surface *surfaces, int64_t n, const rt_camera *cam, cons
     for (int k = 0; k < ncols; k++) {
         const int px = p->x_begin + k * p->x_step;
         octx c; c.surf = surf; c.n = (int)n; c.seed = p->seed; c.max_trace_depth = p->max_trace_depth;
-        c.background = background; c.flags = flags; c.rays = 0;
+        c.background = background; c.flags = flags; c.rays = 0; c.estimator = p->estimator;
         for (int py = 0; py < H; py++) {
             const uint64_t pixel = (uint64_t)px * (uint64_t)H + (uint64_t)py;
             /* Camera.fs:8-17 pertrube, :20-22 PixelToNDC */
@@ -775,6 +827,21 @@ int rto_generate_samples(const rt_surface *a, const float o[3], const float d[3]
     for (int i = 0; i < n; i++) {
         out_dirs[3 * i] = smp[i].ray.d.x; out_dirs[3 * i + 1] = smp[i].ray.d.y; out_dirs[3 * i + 2] = smp[i].ray.d.z;
         out_shading[3 * i] = smp[i].shading.x; out_shading[3 * i + 1] = smp[i].shading.y; out_shading[3 * i + 2] = smp[i].shading.z;
+    }
+    return n;
+}
+/* the same with the single-path estimator (one child; Dielectric through its stochastic Scatter) */
+int rto_generate_samples_single_path(const rt_surface *a, const float o[3], const float d[3], float t,
+                                     uint64_t seed, uint64_t ps, uint64_t node, float out_dir[3], float out_shading[3])
+{
+    osurf s; one_surface(a, &s);
+    octx c; memset(&c, 0, sizeof c); c.seed = seed; c.estimator = RT_ESTIMATOR_SINGLE_PATH;
+    ray_t r; r.o = V3(o[0], o[1], o[2]); r.d = V3(d[0], d[1], d[2]);
+    sample_t smp[4];
+    int n = generate_samples(&c, &s, &r, t, ps, node, smp);
+    if (n > 0) {
+        out_dir[0] = smp[0].ray.d.x; out_dir[1] = smp[0].ray.d.y; out_dir[2] = smp[0].ray.d.z;
+        out_shading[0] = smp[0].shading.x; out_shading[1] = smp[0].shading.y; out_shading[2] = smp[0].shading.z;
     }
     return n;
 }

@@ -15,11 +15,13 @@ RT_E_NO_DEVICE = -2
 RT_E_HIP = -3
 RT_E_OVERFLOW = -4
 RT_E_UNSUPPORTED = -5
+RT_E_RANGE = -6
 
+ESTIMATOR_BRANCHING, ESTIMATOR_SINGLE_PATH = 0, 1
 KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
-RT_ABI_VERSION = 5
+RT_ABI_VERSION = 6
 RT_STATS_WORDS = 16
 
 
@@ -60,6 +62,10 @@ class rt_params(C.Structure):
         ("x_step", C.c_int32),
         ("waves_per_cu", C.c_int32),
         ("pool_blocks", C.c_int32),
+        ("estimator", C.c_int32),
+        ("bvh_ring", C.c_int32),
+        ("bvh_min_active", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -82,13 +88,13 @@ assert surface_dtype.itemsize == C.sizeof(rt_surface), (surface_dtype.itemsize, 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_HIP_PATH = os.path.join(_PKG_DIR, "csrc", "librt_hip.so")
-LIB_HOST_PATH = os.path.join(_PKG_DIR, "host", "librt_host.so")
 
 # every symbol include/rt_abi.h declares
 ABI_SYMBOLS = (
     "rt_scene_create",
     "rt_render",
     "rt_render_device",
+    "rt_render_multi",
     "rt_find_closest",
     "rt_scene_status",
     "rt_scene_destroy",
@@ -119,6 +125,9 @@ def load_hip_library():
     lib.rt_render_device.argtypes = [C.c_void_p, P(rt_camera), P(rt_params), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rt_render_device.restype = C.c_int
+    lib.rt_render_multi.argtypes = [P(C.c_void_p), C.c_int32, P(rt_camera), P(rt_params), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, P(C.c_float), P(C.c_uint64)]
+    lib.rt_render_multi.restype = C.c_int
     lib.rt_find_closest.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rt_find_closest.restype = C.c_int
     lib.rt_scene_status.argtypes = [C.c_void_p]

@@ -44,7 +44,7 @@ struct alignas(16) ShadeRec {
     float albedo[3];      // Material.Albedo
     float param;          // Metal: clamp(fuzz,0,1) (Surface.fs:88); Dielectric: refractive index
     float emission[3];    // Material.Emmitance
-    uint32_t info;        // kind | nsamples << 2 | geom << 5
+    uint32_t info;        // kind | nsamples << 2 | geom << 5 | (Lambertian with the default SampleCount) << 7
     float nc[3];          // sphere: center; plane: Normalize(plane.Normal) (Plane.fs:15)
     uint32_t pad0;
     uint64_t id;          // Surface.ID
@@ -160,12 +160,15 @@ RT_DEV void sincos_2pi(float u, float& s_out, float& c_out)
 
 // RandomSampling.RandomInUnitHemisphere (call sites Surface.fs:72,99): uniform on the y-up
 // hemisphere, .Y = cos(theta) (Surface.fs:73)
-RT_DEV f3 hemisphere_sample(uint32_t seed_lo, uint32_t seed_hi, uint64_t ps, uint64_t node)
+// `rf` receives the third word of the same Philox block as a float in [0,1): RandomSampling.RandomFloat
+// (call site Surface.fs:157), used by the single-path estimator's Dielectric.Scatter.
+RT_DEV f3 hemisphere_sample(uint32_t seed_lo, uint32_t seed_hi, uint64_t ps, uint64_t node, float& rf)
 {
     uint32_t w0, w1, w2, w3;
     philox4x32_10((uint32_t)ps, (uint32_t)(ps >> 32), (uint32_t)node, (uint32_t)(node >> 32), seed_lo, seed_hi,
                   w0, w1, w2, w3);
     float r1 = u01(w0), r2 = u01(w1);
+    rf = u01(w2);
     float sin_theta = sqrt_rn(1.0f - r1 * r1);
     float s, c;
     sincos_2pi(r2, s, c);

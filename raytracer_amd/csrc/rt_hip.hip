@@ -96,8 +96,9 @@ int default_samples(int kind, int sample_count, int lambertian_default)
 struct rt_scene {
     int device = 0;
     int64_t n = 0;
+    hipStream_t stream = nullptr;              // rt_render / rt_find_closest / rt_render_multi work of this scene
     GeomRec* d_geom = nullptr;
-    ShadeRec* d_shade[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // index = Lambertian SampleCount default (1..4)
+    ShadeRec* d_shade = nullptr;
     int* d_status = nullptr;
     unsigned long long* d_counter = nullptr;   // work counter of the persistent waves
     unsigned long long* d_accum = nullptr;     // per-pixel 32.32 radiance sums (grown on demand)
@@ -109,41 +110,29 @@ struct rt_scene {
     int num_cus = 0;
     int64_t nloose = 0;                        // entries of d_geom (all surfaces, or only the planes of a BVH scene)
     bool use_bvh = false;
+    int spill_factor = 1;                      // BVH scenes: multiple of the in-order pool bound the spill area holds
     float4* d_nodes = nullptr; float4* d_pdata = nullptr;
     int nnodes = 0, bvh_depth = 0;
     int64_t nprims = 0;                        // primitives in the BVH
-    int occ_smem[2] = { -1, -1 };              // LDS size the cached occupancy below was queried for
-    int occ_per_cu[2] = { 0, 0 };
+    int occ_smem[4] = { -1, -1, -1, -1 };      // LDS size the cached occupancy below was queried for (per kernel variant)
+    int occ_per_cu[4] = { 0, 0, 0, 0 };
     float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
     size_t tmp_bytes = 0;
-    std::vector<ShadeRec> h_shade;      // with nsamples of Lambertian-default surfaces left 0
-    std::vector<int> lamb_default;      // surfaces whose Lambertian SampleCount follows rt_params
+    float* d_frame = nullptr;           // rt_render_multi: the gathered frame on the root scene's device
+    size_t frame_bytes = 0;
 };
 
 namespace {
 
-int ensure_tmp(rt_scene* sc, size_t bytes)
+int ensure_buffer(void** ptr, size_t* have, size_t bytes)
 {
-    if (sc->tmp_bytes >= bytes) return RT_OK;
-    if (sc->d_tmp) { HIP_TRY(hipFree(sc->d_tmp)); sc->d_tmp = nullptr; sc->tmp_bytes = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_tmp), bytes));
-    sc->tmp_bytes = bytes;
+    if (*have >= bytes) return RT_OK;
+    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(ptr, bytes));
+    *have = bytes;
     return RT_OK;
 }
-
-// ShadeRec table for one value of the Lambertian SampleCount default (uploaded on first use)
-int shade_table(rt_scene* sc, int lamb, const ShadeRec** out)
-{
-    if (!sc->d_shade[lamb]) {
-        std::vector<ShadeRec> h = sc->h_shade;
-        for (int i : sc->lamb_default) h[i].info |= (uint32_t)lamb << 2;
-        const size_t bytes = sizeof(ShadeRec) * (h.empty() ? 1 : h.size());
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_shade[lamb]), bytes));
-        if (!h.empty()) HIP_TRY(hipMemcpy(sc->d_shade[lamb], h.data(), sizeof(ShadeRec) * h.size(), hipMemcpyHostToDevice));
-    }
-    *out = sc->d_shade[lamb];
-    return RT_OK;
-}
+int ensure_tmp(rt_scene* sc, size_t bytes) { return ensure_buffer(reinterpret_cast<void**>(&sc->d_tmp), &sc->tmp_bytes, bytes); }
 
 int check_params(const rt_camera* cam, const rt_params* p)
 {
@@ -155,33 +144,10 @@ int check_params(const rt_camera* cam, const rt_params* p)
         return fail(RT_E_INVALID, "bad column range x_begin/x_end/x_step");
     if (p->waves_per_cu < 0 || p->waves_per_cu > 32) return fail(RT_E_INVALID, "waves_per_cu must be in 0..32");
     if (p->pool_blocks < 0 || p->pool_blocks > 32) return fail(RT_E_INVALID, "pool_blocks must be in 0..32");
-    return RT_OK;
-}
-
-int ensure_accum(rt_scene* sc, size_t bytes)
-{
-    if (sc->accum_bytes >= bytes) return RT_OK;
-    if (sc->d_accum) { HIP_TRY(hipFree(sc->d_accum)); sc->d_accum = nullptr; sc->accum_bytes = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_accum), bytes));
-    sc->accum_bytes = bytes;
-    return RT_OK;
-}
-
-int ensure_spill(rt_scene* sc, size_t bytes)
-{
-    if (sc->spill_bytes >= bytes) return RT_OK;
-    if (sc->d_spill) { HIP_TRY(hipFree(sc->d_spill)); sc->d_spill = nullptr; sc->spill_bytes = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_spill), bytes));
-    sc->spill_bytes = bytes;
-    return RT_OK;
-}
-
-int ensure_gstack(rt_scene* sc, size_t bytes)
-{
-    if (sc->gstack_bytes >= bytes) return RT_OK;
-    if (sc->d_gstack) { HIP_TRY(hipFree(sc->d_gstack)); sc->d_gstack = nullptr; sc->gstack_bytes = 0; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc->d_gstack), bytes));
-    sc->gstack_bytes = bytes;
+    if (p->estimator != RT_ESTIMATOR_BRANCHING && p->estimator != RT_ESTIMATOR_SINGLE_PATH) return fail(RT_E_INVALID, "estimator must be 0 or 1");
+    if (p->bvh_ring != 0 && p->bvh_ring != 8 && p->bvh_ring != 16) return fail(RT_E_INVALID, "bvh_ring must be 0, 8 or 16");
+    if (p->bvh_min_active < 0 || p->bvh_min_active > 64) return fail(RT_E_INVALID, "bvh_min_active must be in 0..64");
+    if (p->reserved != 0) return fail(RT_E_INVALID, "reserved must be 0");
     return RT_OK;
 }
 
@@ -192,15 +158,22 @@ BvhRef bvh_ref(const rt_scene* sc)
     return b;
 }
 
+// refill threshold of the BVH kernels (lanes still walking); a wave needs a free sample slot to start a primary ray,
+// so the default must not exceed the sample slots of any variant (the kernel makes progress either way, see
+// trace_kernel "leave early", but a larger value only costs occupancy of the lanes)
+constexpr int kMinActiveDefault = 28;
+static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slots_of(true, 16), "refill threshold above the sample slots");
+
 template <bool NODE64, bool BVH, int RING>
-int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec* shade, int waves_per_cu,
+int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_cu,
                  size_t smem, hipStream_t stream)
 {
     const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING>);
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     // the attribute and the occupancy query cost host time: once per (kernel, LDS size) and scene
-    int& cached_smem = sc->occ_smem[NODE64 ? 1 : 0];
-    int& cached_per_cu = sc->occ_per_cu[NODE64 ? 1 : 0];
+    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0);
+    int& cached_smem = sc->occ_smem[variant];
+    int& cached_per_cu = sc->occ_per_cu[variant];
     if (cached_smem != (int)smem) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int q = 0;
@@ -217,16 +190,18 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, const ShadeRec*
     // dynamic balancing left and the waves that drew expensive pixels finish alone (measured: mean wave lifetime
     // 0.59 ms of a 1.13 ms kernel).  Two thirds as many waves as refills balances better: 13.8 -> 15.0 Grays/s.
     if (grid * 3 > chunks * 2) grid = std::max<unsigned long long>(chunks * 2 / 3, 1ull);
-    int rc = ensure_spill(sc, (size_t)grid * a.max_spill * NF * 64 * sizeof(uint32_t));
+    const size_t wave_spill = (size_t)a.max_spill * NF * 64 * sizeof(uint32_t);
+    const size_t wave_stack = BVH ? (size_t)kBvhStack * 64 * sizeof(uint32_t) : 0;
+    int rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_spill), &sc->spill_bytes, (size_t)grid * wave_spill);
     if (rc) return rc;
     c.spill = sc->d_spill;
     c.gstack = nullptr;
     if (BVH) {
-        rc = ensure_gstack(sc, (size_t)grid * kBvhStack * 64 * sizeof(uint32_t));
+        rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_gstack), &sc->gstack_bytes, (size_t)grid * wave_stack);
         if (rc) return rc;
         c.gstack = sc->d_gstack;
     }
-    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, shade,
+    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
                        bvh_ref(sc));
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -237,6 +212,141 @@ constexpr int64_t kBvhThreshold = 64;
 constexpr int64_t kLooseSpheres = 16;
 // Up to this many primitives the 8-entry stack ring is used (measured: 100k triangles +2..10 %, 1M spheres -11 %).
 constexpr int64_t kBvhSmallTree = 262144;
+
+int columns_of(const rt_params* p) { return (p->x_end - p->x_begin + p->x_step - 1) / p->x_step; }
+
+// The render behind rt_render_device: memsets, trace_kernel, resolve_kernel on `stream`.
+int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hipStream_t stream,
+                     float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats)
+{
+    if (!sc) return fail(RT_E_INVALID, "scene is null");
+    int rc = check_params(cam, p);
+    if (rc) return rc;
+    if (!d_rgba || !d_depth) return fail(RT_E_INVALID, "rgba and depth buffers are required");
+    HIP_TRY(hipSetDevice(sc->device));
+
+    const int ncols = columns_of(p);
+    if (ncols <= 0) return RT_OK;
+    const long long npix = (long long)ncols * p->height;
+    if (npix > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
+    const size_t accum_bytes = (size_t)npix * 4 * sizeof(unsigned long long);
+    int rc2 = ensure_buffer(reinterpret_cast<void**>(&sc->d_accum), &sc->accum_bytes, accum_bytes);
+    if (rc2) return rc2;
+    unsigned long long* accum = sc->d_accum;
+
+    RenderArgs a; memset(&a, 0, sizeof a);
+    ColdArgs c; memset(&c, 0, sizeof c);
+    c.accum = accum; c.counter = sc->d_counter; c.depth = d_depth;
+    c.ids = reinterpret_cast<unsigned long long*>(d_object_id);
+    c.stats = reinterpret_cast<unsigned long long*>(d_stats);
+    c.status = sc->d_status;
+    c.total = (unsigned long long)npix * (unsigned long long)p->spp;
+    c.npix = (unsigned int)npix;
+    {   // multiplier of the hand-out permutation: near npix/phi, coprime with npix
+        unsigned long long m = (unsigned long long)((double)npix * 0.6180339887498949) | 1ull;
+        auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long t = x % y; x = y; y = t; } return x; };
+        while (gcd(m, (unsigned long long)npix) != 1) m += 2;
+        c.scatter = (unsigned int)(m % (unsigned long long)npix);
+        if (npix == 1) c.scatter = 0;
+    }
+    a.nsurf = (int)sc->nloose; c.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
+    c.jitter = p->jitter ? 1 : 0;
+    a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
+    c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
+    a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
+    a.lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
+    a.estimator = p->estimator;
+    // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
+    // 28 of its lanes still walk the tree; a group of lanes steps once 16 of them have gathered
+    a.min_active = p->bvh_min_active > 0 ? p->bvh_min_active : kMinActiveDefault;
+    a.leaf_min = 16;
+    for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
+    // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
+    // (DESIGN.md "Pool bound"); the top pool_blocks blocks live in LDS, the rest spills to HBM
+    const int levels = p->max_trace_depth + 1 + a.bg_nonzero;
+    a.nblk = p->pool_blocks > 0 ? p->pool_blocks : 2;   // measured: 2 blocks (19 waves/CU) beats 3, 4, 6
+    if (a.nblk > levels) a.nblk = levels;
+    if (a.nblk < 2 && levels >= 2) a.nblk = 2;
+    // A BVH scene's rays finish out of order, so records of one level can be pushed while a few suspended rays of
+    // the level above are still walking: the in-order bound does not hold and the capacity is a heuristic
+    // (2x the bound, never seen exceeded); rt_render doubles spill_factor and renders again on RT_E_OVERFLOW.
+    a.max_spill = sc->use_bvh ? 2 * sc->spill_factor * levels : levels;
+
+    // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
+    const float* M = cam->cam_to_world;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.rot[3 * i + j] = M[4 * i + j];
+    c.origin[0] = M[12]; c.origin[1] = M[13]; c.origin[2] = M[14];
+    const H3 ln = hnormalize(H3{ cam->look_at[0], cam->look_at[1], cam->look_at[2] });
+    c.look_n[0] = ln.x; c.look_n[1] = ln.y; c.look_n[2] = ln.z;
+    c.fw = (float)p->width; c.fh = (float)p->height;
+    c.aspect = c.fw / c.fh;
+    c.tan_half = tanf(cam->fov / 2.0f);
+
+    const bool node64 = p->max_trace_depth > 13;
+    const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
+    // LDS entries of the traversal stacks: see trace_kernel's RING
+    const int ring = p->bvh_ring ? p->bvh_ring : (sc->nprims <= kBvhSmallTree) ? 8 : 16;
+    const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring)).pool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * ring : 0));
+    if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
+
+    HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(accum, 0, accum_bytes, stream));
+    if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
+    if (sc->use_bvh)
+        rc = ring == 8 ? (node64 ? launch_trace<true, true, 8>(sc, c, a, p->waves_per_cu, smem, stream)
+                                 : launch_trace<false, true, 8>(sc, c, a, p->waves_per_cu, smem, stream))
+                       : (node64 ? launch_trace<true, true, 16>(sc, c, a, p->waves_per_cu, smem, stream)
+                                 : launch_trace<false, true, 16>(sc, c, a, p->waves_per_cu, smem, stream));
+    else
+        rc = node64 ? launch_trace<true, false, 16>(sc, c, a, p->waves_per_cu, smem, stream)
+                    : launch_trace<false, false, 16>(sc, c, a, p->waves_per_cu, smem, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, accum, d_rgba,
+                       npix, p->spp);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// Status word of the scene's last launch, read on its own stream (0 = OK).
+int status_after(rt_scene* sc, hipStream_t stream, int* raw)
+{
+    int st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, sc->d_status, sizeof st, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (raw) *raw = st;
+    if (st & kStatusOverflow) return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its bound; results are invalid");
+    if (st & kStatusRange) return fail(RT_E_RANGE, "a radiance contribution was not finite or reached 2^31; it was dropped and the image is invalid");
+    return RT_OK;
+}
+
+// Compact staging of one scene's columns inside its d_tmp: stats | ids (8 B each) | rgba (16 B each) | depth (4 B each)
+struct Staging { uint64_t* stats; uint64_t* ids; float* rgba; float* depth; };
+int staging_of(rt_scene* sc, size_t npix, Staging* s)
+{
+    const size_t off_ids = RT_STATS_WORDS * 8, off_rgba = off_ids + npix * 8, off_depth = off_rgba + npix * 16;
+    const int rc = ensure_tmp(sc, off_depth + npix * 4);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(sc->d_tmp);
+    s->stats = reinterpret_cast<uint64_t*>(base); s->ids = reinterpret_cast<uint64_t*>(base + off_ids);
+    s->rgba = reinterpret_cast<float*>(base + off_rgba); s->depth = reinterpret_cast<float*>(base + off_depth);
+    return RT_OK;
+}
+
+// Renders into the scene's staging on its own stream and waits; on a pool overflow of a BVH scene (heuristic capacity)
+// the spill area is doubled and the frame rendered again.
+int render_staged(rt_scene* sc, const rt_camera* cam, const rt_params* p, size_t npix, bool want_ids, Staging* st)
+{
+    int rc = staging_of(sc, npix, st);
+    if (rc) return rc;
+    for (int attempt = 0;; attempt++) {
+        rc = render_on_stream(sc, cam, p, sc->stream, st->rgba, st->depth, want_ids ? st->ids : nullptr, st->stats);
+        if (rc) return rc;
+        rc = status_after(sc, sc->stream, nullptr);
+        if (rc != RT_E_OVERFLOW || !sc->use_bvh || attempt >= 3) return rc;
+        sc->spill_factor *= 2;
+    }
+}
 
 }  // namespace
 
@@ -267,7 +377,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     // A handful of spheres in a mesh scene stay in the scanned list: in the tree each of them is a second kind of
     // leaf step that most rounds would have to run (measured on the 4K mixed scene).
     const bool loose_spheres = any_tri && nsphere <= kLooseSpheres;
-    const bool use_bvh = any_tri || n > kBvhThreshold;
+    // (a scene of many planes and nothing else has no primitive to put in a tree: it is scanned)
+    const bool use_bvh = (any_tri || n > kBvhThreshold) && nprim > 0;
     std::vector<BuildPrim> bprims;
     HostBvh hb;
     std::vector<float4> src_pdata;
@@ -275,7 +386,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     rt_scene* sc = new (std::nothrow) rt_scene;
     if (!sc) return fail(RT_E_INVALID, "out of host memory");
     sc->device = device; sc->n = n; sc->use_bvh = use_bvh;
-    sc->h_shade.resize((size_t)n);
+    std::vector<ShadeRec> h_shade((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         const rt_surface& s = surfaces[i];
         if (s.kind < 0 || s.kind > 3) { delete sc; return fail(RT_E_INVALID, "surface %lld: bad kind %d", (long long)i, s.kind); }
@@ -350,15 +461,16 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
         }
         g.type = gtype;
         g.index = (int32_t)i;
-        int ns = default_samples(s.kind, s.sample_count, 0);
-        if (s.kind == RT_KIND_LAMBERTIAN && s.sample_count == 0) sc->lamb_default.push_back((int)i);
-        h.info = (uint32_t)s.kind | ((uint32_t)ns << 2) | ((uint32_t)gtype << 5);
+        const int ns = default_samples(s.kind, s.sample_count, 0);
+        // a Lambertian without its own SampleCount takes rt_params.lambertian_samples at render time (bit 7)
+        const uint32_t lamb_default = (s.kind == RT_KIND_LAMBERTIAN && s.sample_count == 0) ? 0x80u : 0u;
+        h.info = (uint32_t)s.kind | ((uint32_t)ns << 2) | ((uint32_t)gtype << 5) | lamb_default;
         // the scalar-operand linear list: every surface of a small scene, only the planes of a BVH scene
         if (!use_bvh || s.geom == RT_GEOM_PLANE || (s.geom == RT_GEOM_SPHERE && loose_spheres)) geom.push_back(g);
-        sc->h_shade[(size_t)i] = h;
+        h_shade[(size_t)i] = h;
     }
     sc->nloose = (int64_t)geom.size();
-    if (sc->nloose > kMaxPoolSurfaces) { delete sc; return fail(RT_E_UNSUPPORTED, "more than %d planes", kMaxPoolSurfaces); }
+    if (sc->nloose > kMaxPoolSurfaces) { delete sc; return fail(RT_E_UNSUPPORTED, "more than %d %s", kMaxPoolSurfaces, use_bvh ? "planes" : "surfaces without a sphere or triangle among them"); }
     if (use_bvh) {
         bvh_build(bprims, src_pdata, hb);
         if (3 * hb.depth + 1 > kBvhStack) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
@@ -371,8 +483,11 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
 
     hipError_t e = hipSetDevice(device);
     const size_t ng = geom.size();
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_geom), sizeof(GeomRec) * (ng > 0 ? ng : 1));
     if (e == hipSuccess && ng > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * ng, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_shade), sizeof(ShadeRec) * (n > 0 ? (size_t)n : 1));
+    if (e == hipSuccess && n > 0) e = hipMemcpy(sc->d_shade, h_shade.data(), sizeof(ShadeRec) * (size_t)n, hipMemcpyHostToDevice);
     if (use_bvh && !hb.nodes.empty()) {
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), sizeof(float4) * hb.nodes.size());
         if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), sizeof(float4) * hb.nodes.size(), hipMemcpyHostToDevice);
@@ -396,8 +511,9 @@ void rt_scene_destroy(rt_scene* sc)
 {
     if (!sc) return;
     (void)hipSetDevice(sc->device);
+    if (sc->stream) { (void)hipStreamSynchronize(sc->stream); (void)hipStreamDestroy(sc->stream); }
     if (sc->d_geom) (void)hipFree(sc->d_geom);
-    for (ShadeRec* p : sc->d_shade) if (p) (void)hipFree(p);
+    if (sc->d_shade) (void)hipFree(sc->d_shade);
     if (sc->d_status) (void)hipFree(sc->d_status);
     if (sc->d_counter) (void)hipFree(sc->d_counter);
     if (sc->d_accum) (void)hipFree(sc->d_accum);
@@ -406,100 +522,14 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_nodes) (void)hipFree(sc->d_nodes);
     if (sc->d_pdata) (void)hipFree(sc->d_pdata);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
+    if (sc->d_frame) (void)hipFree(sc->d_frame);
     delete sc;
 }
 
 int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, void* stream_v,
                      float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats)
 {
-    if (!sc) return fail(RT_E_INVALID, "scene is null");
-    int rc = check_params(cam, p);
-    if (rc) return rc;
-    if (!d_rgba || !d_depth) return fail(RT_E_INVALID, "rgba and depth buffers are required");
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    HIP_TRY(hipSetDevice(sc->device));
-
-    const int ncols = (p->x_end - p->x_begin + p->x_step - 1) / p->x_step;
-    if (ncols <= 0) return RT_OK;
-    const long long npix = (long long)ncols * p->height;
-    if (npix > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
-    const int lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
-    const ShadeRec* shade = nullptr;
-    rc = shade_table(sc, lamb, &shade);
-    if (rc) return rc;
-    rc = ensure_accum(sc, (size_t)npix * 4 * sizeof(unsigned long long));
-    if (rc) return rc;
-
-    RenderArgs a; memset(&a, 0, sizeof a);
-    ColdArgs c; memset(&c, 0, sizeof c);
-    c.accum = sc->d_accum; c.counter = sc->d_counter; c.depth = d_depth;
-    c.ids = reinterpret_cast<unsigned long long*>(d_object_id);
-    c.stats = reinterpret_cast<unsigned long long*>(d_stats);
-    c.status = sc->d_status;
-    c.total = (unsigned long long)npix * (unsigned long long)p->spp;
-    c.npix = (unsigned int)npix;
-    {   // multiplier of the hand-out permutation: near npix/phi, coprime with npix
-        unsigned long long m = (unsigned long long)((double)npix * 0.6180339887498949) | 1ull;
-        auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long t = x % y; x = y; y = t; } return x; };
-        while (gcd(m, (unsigned long long)npix) != 1) m += 2;
-        c.scatter = (unsigned int)(m % (unsigned long long)npix);
-        if (npix == 1) c.scatter = 0;
-    }
-    a.nsurf = (int)sc->nloose; c.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
-    c.jitter = p->jitter ? 1 : 0;
-    a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
-    c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
-    a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
-    // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
-    // 28 of its lanes still walk the tree (must not exceed the 32 sample slots of the small-tree variant, see
-    // trace_kernel); a group of lanes steps once 16 of them have gathered
-    a.min_active = 28;
-    a.leaf_min = 16;
-    for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
-    // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
-    // (DESIGN.md "Pool bound"); the top pool_blocks blocks live in LDS, the rest spills to HBM
-    const int levels = p->max_trace_depth + 1 + a.bg_nonzero;
-    a.nblk = p->pool_blocks > 0 ? p->pool_blocks : 2;   // measured: 2 blocks (19 waves/CU) beats 3, 4, 6
-    if (a.nblk > levels) a.nblk = levels;
-    if (a.nblk < 2 && levels >= 2) a.nblk = 2;
-    // (a BVH scene gets twice the proven capacity: its rays finish out of order, so records of one level can be
-    // pushed while a few suspended rays of the level above are still walking)
-    a.max_spill = sc->use_bvh ? 2 * levels : levels;
-
-    // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
-    const float* M = cam->cam_to_world;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.rot[3 * i + j] = M[4 * i + j];
-    c.origin[0] = M[12]; c.origin[1] = M[13]; c.origin[2] = M[14];
-    const H3 ln = hnormalize(H3{ cam->look_at[0], cam->look_at[1], cam->look_at[2] });
-    c.look_n[0] = ln.x; c.look_n[1] = ln.y; c.look_n[2] = ln.z;
-    c.fw = (float)p->width; c.fh = (float)p->height;
-    c.aspect = c.fw / c.fh;
-    c.tan_half = tanf(cam->fov / 2.0f);
-
-    const bool node64 = p->max_trace_depth > 13;
-    const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
-    // LDS entries of the traversal stacks: see trace_kernel's RING
-    const int ring = (sc->nprims <= kBvhSmallTree) ? 8 : 16;
-    const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring)).pool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * ring : 0));
-    if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
-
-    HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
-    HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(sc->d_accum, 0, (size_t)npix * 4 * sizeof(unsigned long long), stream));
-    if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
-    if (sc->use_bvh)
-        rc = ring == 8 ? (node64 ? launch_trace<true, true, 8>(sc, c, a, shade, p->waves_per_cu, smem, stream)
-                                 : launch_trace<false, true, 8>(sc, c, a, shade, p->waves_per_cu, smem, stream))
-                       : (node64 ? launch_trace<true, true, 16>(sc, c, a, shade, p->waves_per_cu, smem, stream)
-                                 : launch_trace<false, true, 16>(sc, c, a, shade, p->waves_per_cu, smem, stream));
-    else
-        rc = node64 ? launch_trace<true, false, 16>(sc, c, a, shade, p->waves_per_cu, smem, stream)
-                    : launch_trace<false, false, 16>(sc, c, a, shade, p->waves_per_cu, smem, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, sc->d_accum, d_rgba,
-                       npix, p->spp);
-    HIP_TRY(hipGetLastError());
-    return RT_OK;
+    return render_on_stream(sc, cam, p, static_cast<hipStream_t>(stream_v), d_rgba, d_depth, d_object_id, d_stats);
 }
 
 int rt_scene_status(rt_scene* sc)
@@ -508,7 +538,8 @@ int rt_scene_status(rt_scene* sc)
     HIP_TRY(hipSetDevice(sc->device));
     int st = 0;
     HIP_TRY(hipMemcpy(&st, sc->d_status, sizeof st, hipMemcpyDeviceToHost));
-    if (st) return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its bound; results are invalid");
+    if (st & kStatusOverflow) return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its bound; results are invalid");
+    if (st & kStatusRange) return fail(RT_E_RANGE, "a radiance contribution was not finite or reached 2^31; it was dropped and the image is invalid");
     return RT_OK;
 }
 
@@ -520,30 +551,106 @@ int rt_render(rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgb
     if (rc) return rc;
     if (!rgba || !depth) return fail(RT_E_INVALID, "rgba and depth buffers are required");
     HIP_TRY(hipSetDevice(sc->device));
-    const size_t ncols = (size_t)((p->x_end - p->x_begin + p->x_step - 1) / p->x_step);
-    const size_t npix = ncols * (size_t)p->height;
+    const size_t npix = (size_t)columns_of(p) * (size_t)p->height;
     if (npix == 0) { if (max_depth) *max_depth = 0.0f; if (ray_count) *ray_count = 0; return RT_OK; }
-    // staging layout: stats | ids (8 B each) | rgba (16 B each) | depth (4 B each)
-    const size_t off_ids = RT_STATS_WORDS * 8, off_rgba = off_ids + npix * 8, off_depth = off_rgba + npix * 16;
-    rc = ensure_tmp(sc, off_depth + npix * 4);
+    Staging st;
+    rc = render_staged(sc, cam, p, npix, object_id != nullptr, &st);
     if (rc) return rc;
-    char* base = reinterpret_cast<char*>(sc->d_tmp);
-    uint64_t* d_stats = reinterpret_cast<uint64_t*>(base);
-    uint64_t* d_ids = reinterpret_cast<uint64_t*>(base + off_ids);
-    float* d_rgba = reinterpret_cast<float*>(base + off_rgba);
-    float* d_depth = reinterpret_cast<float*>(base + off_depth);
-    rc = rt_render_device(sc, cam, p, nullptr, d_rgba, d_depth, object_id ? d_ids : nullptr, d_stats);
+    // the scene's own stream: other scenes on this device keep running (no device-wide synchronisation)
+    uint64_t stats[2];
+    HIP_TRY(hipMemcpyAsync(rgba, st.rgba, npix * 16, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipMemcpyAsync(depth, st.depth, npix * 4, hipMemcpyDeviceToHost, sc->stream));
+    if (object_id) HIP_TRY(hipMemcpyAsync(object_id, st.ids, npix * 8, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipMemcpyAsync(stats, st.stats, sizeof stats, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    if (ray_count) *ray_count = stats[0];
+    if (max_depth) { uint32_t bits = (uint32_t)stats[1]; memcpy(max_depth, &bits, 4); }
+    g_err[0] = 0;
+    return RT_OK;
+}
+
+// Scene i of n renders the columns i, i+n, ... on its own device and stream; a placement kernel on that device then
+// stores its compact block at stride n into the frame that lives in the HBM of scenes[0]'s device (peer stores over
+// xGMI when the devices differ), and the gathered frame is copied to the host once.
+int rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* cam, const rt_params* p,
+                    float* rgba, float* depth, uint64_t* object_id, float* max_depth, uint64_t* ray_count)
+{
+    if (!scenes || nscenes <= 0) return fail(RT_E_INVALID, "no scenes");
+    for (int i = 0; i < nscenes; i++) if (!scenes[i]) return fail(RT_E_INVALID, "scene %d is null", i);
+    int rc = check_params(cam, p);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    rc = rt_scene_status(sc);
+    if (!rgba || !depth) return fail(RT_E_INVALID, "rgba and depth buffers are required");
+    if (p->x_begin != 0 || p->x_end != p->width || p->x_step != 1)
+        return fail(RT_E_INVALID, "rt_render_multi partitions the whole frame itself: x_begin/x_end/x_step must be 0/width/1");
+    for (int i = 0; i < nscenes; i++)
+        for (int j = 0; j < i; j++)
+            if (scenes[i] == scenes[j]) return fail(RT_E_INVALID, "scene %d given twice (a handle renders one frame at a time)", i);
+    rt_scene* root = scenes[0];
+    const int W = p->width, H = p->height;
+    const size_t fpix = (size_t)W * (size_t)H;
+    // the gathered frame on the root device: rgba | ids | depth
+    HIP_TRY(hipSetDevice(root->device));
+    rc = ensure_buffer(reinterpret_cast<void**>(&root->d_frame), &root->frame_bytes, fpix * 28);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(rgba, d_rgba, npix * 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(depth, d_depth, npix * 4, hipMemcpyDeviceToHost));
-    if (object_id) HIP_TRY(hipMemcpy(object_id, d_ids, npix * 8, hipMemcpyDeviceToHost));
-    uint64_t st[2];
-    HIP_TRY(hipMemcpy(st, d_stats, sizeof st, hipMemcpyDeviceToHost));
-    if (ray_count) *ray_count = st[0];
-    if (max_depth) { uint32_t bits = (uint32_t)st[1]; memcpy(max_depth, &bits, 4); }
+    float* f_rgba = root->d_frame;
+    uint64_t* f_ids = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(root->d_frame) + fpix * 16);
+    float* f_depth = reinterpret_cast<float*>(reinterpret_cast<char*>(root->d_frame) + fpix * 24);
+    std::vector<Staging> st((size_t)nscenes);
+    std::vector<int> ncols((size_t)nscenes, 0);
+    // 1. every scene starts its share (asynchronous: the devices render concurrently) and queues its placement
+    for (int i = 0; i < nscenes; i++) {
+        rt_scene* sc = scenes[i];
+        rt_params pi = *p;
+        pi.x_begin = i; pi.x_step = nscenes;
+        ncols[(size_t)i] = i < W ? columns_of(&pi) : 0;
+        if (ncols[(size_t)i] <= 0) continue;
+        HIP_TRY(hipSetDevice(sc->device));
+        if (sc->device != root->device) {
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, sc->device, root->device));
+            if (!can) return fail(RT_E_UNSUPPORTED, "device %d cannot store to device %d (no peer access)", sc->device, root->device);
+            const hipError_t pe = hipDeviceEnablePeerAccess(root->device, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(RT_E_HIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(pe));
+            (void)hipGetLastError();
+        }
+        const size_t npix = (size_t)ncols[(size_t)i] * (size_t)H;
+        rc = staging_of(sc, npix, &st[(size_t)i]);
+        if (rc) return rc;
+        rc = render_on_stream(sc, cam, &pi, sc->stream, st[(size_t)i].rgba, st[(size_t)i].depth, object_id ? st[(size_t)i].ids : nullptr,
+                              st[(size_t)i].stats);
+        if (rc) return rc;
+        const long long quads = (long long)npix;
+        hipLaunchKernelGGL(place_columns_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, sc->stream,
+                           st[(size_t)i].rgba, st[(size_t)i].depth,
+                           object_id ? reinterpret_cast<const unsigned long long*>(st[(size_t)i].ids) : nullptr,
+                           f_rgba, f_depth, object_id ? reinterpret_cast<unsigned long long*>(f_ids) : nullptr,
+                           ncols[(size_t)i], H, i, nscenes);
+        HIP_TRY(hipGetLastError());
+    }
+    // 2. wait for every share, reduce the scalars (maxFrameBufferDepth: max, Scene.fs:47-48; ray count: sum)
+    uint64_t rays = 0; float maxd = 0.0f;
+    int first_err = RT_OK;
+    for (int i = 0; i < nscenes; i++) {
+        if (ncols[(size_t)i] <= 0) continue;
+        rt_scene* sc = scenes[i];
+        HIP_TRY(hipSetDevice(sc->device));
+        uint64_t stats[2];
+        HIP_TRY(hipMemcpyAsync(stats, st[(size_t)i].stats, sizeof stats, hipMemcpyDeviceToHost, sc->stream));
+        rc = status_after(sc, sc->stream, nullptr);
+        if (rc && !first_err) first_err = rc;
+        rays += stats[0];
+        uint32_t bits = (uint32_t)stats[1]; float m; memcpy(&m, &bits, 4);
+        maxd = std::max(maxd, m);
+    }
+    if (first_err) return first_err;
+    // 3. one copy of the gathered frame to the host
+    HIP_TRY(hipSetDevice(root->device));
+    HIP_TRY(hipMemcpyAsync(rgba, f_rgba, fpix * 16, hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipMemcpyAsync(depth, f_depth, fpix * 4, hipMemcpyDeviceToHost, root->stream));
+    if (object_id) HIP_TRY(hipMemcpyAsync(object_id, f_ids, fpix * 8, hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    if (ray_count) *ray_count = rays;
+    if (max_depth) *max_depth = maxd;
     g_err[0] = 0;
     return RT_OK;
 }
@@ -558,16 +665,16 @@ int rt_find_closest(rt_scene* sc, int64_t nrays, const float* origins, const flo
     int rc = ensure_tmp(sc, n * 32);
     if (rc) return rc;
     float* d_o = sc->d_tmp; float* d_d = d_o + 3 * n; float* d_t = d_d + 3 * n; int* d_i = reinterpret_cast<int*>(d_t + n);
-    HIP_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_d, directions, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, sc->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, directions, n * 12, hipMemcpyHostToDevice, sc->stream));
     const long long blocks = ((long long)n + 255) / 256;
     if (blocks > 0x7fffffffLL) return fail(RT_E_INVALID, "too many rays for one launch");
-    hipLaunchKernelGGL(find_closest_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, sc->d_geom, (int)sc->nloose,
+    hipLaunchKernelGGL(find_closest_kernel, dim3((unsigned)blocks), dim3(256), 0, sc->stream, sc->d_geom, (int)sc->nloose,
                        bvh_ref(sc), (long long)n, d_o, d_d, d_t, d_i);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(index, d_i, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(t, d_t, n * 4, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipMemcpyAsync(index, d_i, n * 4, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
     g_err[0] = 0;
     return RT_OK;
 }

@@ -60,6 +60,8 @@ struct RenderArgs {
     uint32_t seed_lo, seed_hi;
     int min_active;                 // BVH: leave the traversal when fewer lanes than this are still walking
     int leaf_min;                   // BVH: lanes that must wait at a leaf before the leaves are tested
+    int lamb;                       // SampleCount of Lambertian surfaces that do not override it (Surface.fs:63: 4)
+    int estimator;                  // RT_ESTIMATOR_*: 0 = the reference's branching estimator, 1 = single path
 };
 
 RT_DEV const ColdArgs* cold_args()
@@ -68,6 +70,10 @@ RT_DEV const ColdArgs* cold_args()
     asm volatile("" : "+s"(p));     // opaque: plain global loads at the point of use, never hoisted
     return reinterpret_cast<const ColdArgs*>(p);
 }
+
+// bits of the status word a launch leaves behind (rt_scene_status)
+constexpr int kStatusOverflow = 1;      // a wave's record pool overflowed
+constexpr int kStatusRange = 2;         // a radiance contribution was NaN, infinite or >= 2^31 and was dropped
 
 // meta word of a record
 //   bits 0..7 slot | 8..12 level | 13..15 children | 16..17 kind | 18..19 geometry type | 20..31 surface index
@@ -83,15 +89,22 @@ RT_DEV int mbcnt64(unsigned long long m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// radiance contribution -> signed 32.32 fixed point (two's complement in a u64); |x| < 2^31
+// radiance contribution -> signed 32.32 fixed point (two's complement in a u64).  Defined for finite |x| < 2^31
+// (the callers check that and flag anything else, see add_radiance); contributions below 2^-32 truncate toward
+// minus infinity, like every other bit below the quantum.
 RT_DEV unsigned long long to_fixed(float x)
 {
-    const float fl = floorf(x);
-    const float fr = x - fl;                                    // exact, in [0,1)
-    const uint32_t lo = (uint32_t)(fr * 4294967296.0f);         // exact scaling, truncating convert
+    float fl = floorf(x);
+    float fr = x - fl;                                          // in [0,1]: exactly 1.0 only when a tiny negative x
+    const bool carry = fr >= 1.0f;                              // rounds up in the subtraction (x = -1e-10: -1 + 1.0)
+    fl = carry ? fl + 1.0f : fl;
+    fr = carry ? 0.0f : fr;
+    const uint32_t lo = (uint32_t)(fr * 4294967296.0f);         // exact scaling, truncating convert, < 2^32
     const int32_t hi = (int32_t)fl;
     return ((unsigned long long)(uint32_t)hi << 32) | lo;
 }
+// |x| < 2^31 and not NaN
+RT_DEV bool fixed_ok(f3 v) { return fabsf(v.x) < 2147483648.0f && fabsf(v.y) < 2147483648.0f && fabsf(v.z) < 2147483648.0f; }
 
 // pixel-samples a wave can have in flight: 32 (ray trees widen fast enough to fill the lanes from 32 samples, and
 // the smaller slot table buys waves: linear-scan kernel 8.4 -> 7.2 KB of LDS, 19 -> 22 waves/CU, c4s +6 %; small-
@@ -147,6 +160,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         b = (b >= a.nblk) ? b - a.nblk : b;
         return pool + (b * (NF * 64) + (r & 63));
     };
+    bool range_err = false;                     // a radiance contribution was NaN, infinite or >= 2^31
+    // beta*E into the pixel-sample's fixed-point sum; a contribution the format cannot hold is dropped and flagged
+    auto add_radiance = [&](int sl, f3 v) {
+        if (fixed_ok(v)) {
+            atomicAdd(&sl_acc[sl * 3 + 0], to_fixed(v.x));
+            atomicAdd(&sl_acc[sl * 3 + 1], to_fixed(v.y));
+            atomicAdd(&sl_acc[sl * 3 + 2], to_fixed(v.z));
+        } else range_err = true;
+    };
     enum { F_PX = 0, F_PY = 64, F_PZ = 128, F_DX = 192, F_DY = 256, F_DZ = 320, F_BX = 384, F_BY = 448, F_BZ = 512,
            F_META = 576, F_NODE = 640, F_NODEHI = 704, F_SURF = NODE64 ? 768 : 704 };
     uint32_t* bvh_stack = pool + a.nblk * (NF * 64) + lane;          // [RING][64], only when BVH
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     const unsigned long long t_start = __builtin_readcyclecounter();
 
     int top = 0;                                // records in the pool (wave-uniform)
-    unsigned long long freemask = SLOTS == 64 ? ~0ull : ((1ull << SLOTS) - 1ull);   // free slots (wave-uniform)
+    unsigned long long freemask = ~0ull >> (64 - SLOTS);   // free slots (wave-uniform)
     unsigned long long res_next = 0;            // first pixel-sample of the current refill
     bool exhausted = false;                     // the global counter has run past the end
     uint32_t nrays = 0;                         // closest-hit queries by this lane
@@ -344,10 +366,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             alive = true;
             f3 w = n1;              // the vector whose Normalize gives the scattered / modified / refracted direction
             float cos_l = 0.0f;     // Lambertian: cos(theta) = sample.Y (Surface.fs:73)
+            // one Philox block per child ray: the hemisphere sample of Lambertian / Metal and, under the single-path
+            // estimator, the RandomFloat of Dielectric.Scatter (Surface.fs:157); the branching Dielectric draws nothing
+            f3 rn = F3(0.0f, 1.0f, 0.0f);
+            float rand_float = 0.0f;
+            if ((kind != kKindDielectric) | (a.estimator != 0)) rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode, rand_float);
             if (kind != kKindDielectric) {
                 // Lambertian.Scatter (Surface.fs:66-83) / Metal.Scatter (Surface.fs:93-109): hemisphere
                 // sample in the frame around the normal
-                const f3 rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode);
                 f3 nt, nb;
                 frame_around(n1, nt, nb);
                 // Vector4.Transform(rn, ChangeOfBase nt n nb): rows nt, n, nb; M4x = 0
@@ -359,8 +385,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 cos_l = rn.y;
             }
             float F = 1.0f; bool single = true;
+            bool refr_pick = (child == 1);      // this lane follows the refracted ray
             if (kind == kKindDielectric) {
-                // Surface.fs:124-153 CalcFresnel + :168-181 GenerateSamples
+                // Surface.fs:124-153 CalcFresnel + :168-181 GenerateSamples (branching) / :155-166 Scatter (single path)
                 float eta_i, eta_t; f3 fn;
                 if (dot(Din, n1) > 0.0f) { eta_i = al.w; eta_t = 1.0f; fn = neg(n1); }
                 else                     { eta_i = 1.0f; eta_t = al.w; fn = n1; }
@@ -374,13 +401,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 }
                 single = rounds_to(F, 1e3f, 1e3f);                  // Round(F,3) = 1: reflection only
                 w = (Din + fn * cos_i) * eta - fn * sqrt_rn(disc);  // refraction direction before Normalize
-                if (child == 1) alive = !single;
+                if (a.estimator) refr_pick = !(rand_float <= F);    // Surface.fs:158: reflect when RandomFloat <= reflectProb (F = 1 under TIR)
+                else if (child == 1) alive = !single;
             }
             const f3 u = normalize(w);
             // Metal reflects about the fuzzed normal u, Dielectric about n1; Lambertian keeps u
             f3 r = u;
             if (kind != kKindLambert) r = normalize(reflect(Din, (kind == kKindMetal) ? u : n1));
-            const bool use_u = (kind == kKindLambert) | ((kind == kKindDielectric) & (child == 1));
+            const bool use_u = (kind == kKindLambert) | ((kind == kKindDielectric) & refr_pick);
             Dn = make_ray_dir(use_u ? u : r);
 
             f3 shd;                 // shading_i; folded into beta below
@@ -392,7 +420,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             } else if (kind == kKindMetal) {
                 shd = albedo * (1.0f / 1.0f);
             } else {
-                shd = albedo * ((child == 0) ? F : (1.0f - F));   // (2*albedo*F)/2 == albedo*F exactly
+                // branching: (2*albedo*F)/2 == albedo*F exactly; single path: BRDF*(cos/PDF) = albedo*(1/1) (Surface.fs:28,162)
+                shd = albedo * (a.estimator ? (1.0f / 1.0f) : (child == 0) ? F : (1.0f - F));
             }
             if (kind != kKindDielectric)
                 inv_n = (n == 1) ? 1.0f : (n == 2) ? 0.5f : (n == 3) ? (1.0f / 3.0f) : 0.25f;   // 1/n, correctly rounded
@@ -402,9 +431,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 // depth guard (Scene.fs:52-54): the child returns backgroundColor unintersected
                 alive = false;
                 const ColdArgs* ca = cold_args();
-                atomicAdd(&sl_acc[slot * 3 + 0], to_fixed(beta.x * ca->bg[0]));
-                atomicAdd(&sl_acc[slot * 3 + 1], to_fixed(beta.y * ca->bg[1]));
-                atomicAdd(&sl_acc[slot * 3 + 2], to_fixed(beta.z * ca->bg[2]));
+                add_radiance(slot, beta * F3(ca->bg[0], ca->bg[1], ca->bg[2]));
             }
         }
 
@@ -416,10 +443,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         bool push = false;
         f3 P = F3(0, 0, 0);
         uint32_t hinfo = 0;
+        int hn = 0;                             // children of the hit this lane found
         RT_PHASE(ph_gen)
         if (alive && !busy) {
             closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
-            trav_cur = 0u; trav_sp = 0; trav_lo = 0;   // BVH: start at the root
+            trav_cur = (BVH && bvh.nnodes) ? 0u : kBvhDone; trav_sp = 0; trav_lo = 0;   // BVH: start at the root (an empty tree has none)
             nrays++;
         }
         RT_PHASE(ph_scan)
@@ -455,21 +483,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 if (hit) maxd = fmaxf(maxd, t);
             }
             if (hit) {
-                if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
-                    atomicAdd(&sl_acc[slot * 3 + 0], to_fixed(beta.x * em.x));
-                    atomicAdd(&sl_acc[slot * 3 + 1], to_fixed(beta.y * em.y));
-                    atomicAdd(&sl_acc[slot * 3 + 2], to_fixed(beta.z * em.z));
-                }
-                const int hn = (hinfo >> 2) & 7;
+                if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) add_radiance(slot, beta * F3(em.x, em.y, em.z));
+                // SampleCount of the surface hit (Surface.fs:20,63,92,115); the single-path estimator takes one child
+                hn = (hinfo >> 2) & 7;
+                if (hinfo & 0x80u) hn = a.lamb;
+                if (a.estimator) hn = min(hn, 1);
                 // children of a hit at level max_depth+1 are all cut by the depth guard; with a black
                 // background they contribute exactly 0 and are skipped
                 push = hn > 0 && (clevel <= a.max_depth || a.bg_nonzero);
                 P = O + Dn * t;                                        // Core.fs:59
             } else if (a.bg_nonzero) {
                 const ColdArgs* ca = cold_args();
-                atomicAdd(&sl_acc[slot * 3 + 0], to_fixed(beta.x * ca->bg[0]));
-                atomicAdd(&sl_acc[slot * 3 + 1], to_fixed(beta.y * ca->bg[1]));
-                atomicAdd(&sl_acc[slot * 3 + 2], to_fixed(beta.z * ca->bg[2]));
+                add_radiance(slot, beta * F3(ca->bg[0], ca->bg[1], ca->bg[2]));
             }
         }
         // ---- compaction: hits on scattering surfaces become records, deepest on top
@@ -495,7 +520,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 wb[F_PX] = __float_as_uint(P.x); wb[F_PY] = __float_as_uint(P.y); wb[F_PZ] = __float_as_uint(P.z);
                 wb[F_DX] = __float_as_uint(Dn.x); wb[F_DY] = __float_as_uint(Dn.y); wb[F_DZ] = __float_as_uint(Dn.z);
                 wb[F_BX] = __float_as_uint(beta.x); wb[F_BY] = __float_as_uint(beta.y); wb[F_BZ] = __float_as_uint(beta.z);
-                wb[F_META] = make_meta(slot, clevel, (hinfo >> 2) & 7, hinfo & 3, (hinfo >> 5) & 3, BVH ? 0 : hidx);
+                wb[F_META] = make_meta(slot, clevel, hn, hinfo & 3, (hinfo >> 5) & 3, BVH ? 0 : hidx);
                 if (BVH) wb[F_SURF] = (uint32_t)hidx;
                 wb[F_NODE] = (uint32_t)cnode;
                 if (NODE64) wb[F_NODEHI] = (uint32_t)(cnode >> 32);
@@ -565,7 +590,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             }
         }
     }
-    if (overflow && lane == 0) atomicExch(ca->status, 1);
+    if (overflow && lane == 0) atomicOr(ca->status, kStatusOverflow);
+    if (__ballot(range_err) != 0ull && lane == 0) atomicOr(ca->status, kStatusRange);
 }
 
 // Scene.fs:109,114: mean over samples, gamma 2, alpha 1.  One thread per pixel.
@@ -582,6 +608,23 @@ __global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* 
     }
     const f3 avg = divs(F3(c[0], c[1], c[2]), (float)spp);
     *reinterpret_cast<float4*>(rgba + 4 * o) = make_float4(sqrtf(avg.x), sqrtf(avg.y), sqrtf(avg.z), 1.0f);
+}
+
+// rt_render_multi: the compact [ncols][H] block of partition `r` of `n` (columns r, r+n, ...) goes to its columns of
+// the whole [W][H] frame (Array2D layout px*H + py, Scene.fs:28).  The frame may live in the HBM of another GPU: the
+// stores then travel over xGMI as 16-byte peer writes, consecutive threads to consecutive addresses along py.
+__global__ __launch_bounds__(256) void place_columns_kernel(const float* __restrict__ rgba, const float* __restrict__ depth,
+                                                            const unsigned long long* __restrict__ ids,
+                                                            float* __restrict__ f_rgba, float* __restrict__ f_depth,
+                                                            unsigned long long* __restrict__ f_ids, int ncols, int H, int r, int n)
+{
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long long)ncols * H) return;
+    const int k = (int)(o / H), py = (int)(o - (long long)k * H);
+    const long long dst = (long long)(r + k * n) * H + py;
+    *reinterpret_cast<float4*>(f_rgba + 4 * dst) = *reinterpret_cast<const float4*>(rgba + 4 * o);
+    f_depth[dst] = depth[o];
+    if (ids) f_ids[dst] = ids[o];
 }
 
 // findClosestIntersection as a batch query (Surface.fs:49-58): one ray per thread.

@@ -17,7 +17,8 @@ from . import abi, host
 class Scene:
     def __init__(self, surfaces=None, width=800, height=640, samplesPerPixel=1, maxTraceDepth=5,
                  backgroundColor=(0.0, 0.0, 0.0), cameraOriginWS=(-3.0, 6.0, 15.0), lookAt=(-1.0, 1.0, -10.0),
-                 fov=None, seed=1, jitter=1, lambertian_samples=0, device=0, waves_per_cu=0, pool_blocks=0):
+                 fov=None, seed=1, jitter=1, lambertian_samples=0, device=0, waves_per_cu=0, pool_blocks=0,
+                 estimator=0, bvh_ring=0, bvh_min_active=0):
         if isinstance(surfaces, np.ndarray):
             self.surfaces = np.ascontiguousarray(surfaces)          # flat rt_surface records (raytracer_amd.scenes)
         else:
@@ -28,6 +29,7 @@ class Scene:
         self.camera = host.make_camera(cameraOriginWS, lookAt, (0.0, 1.0, 0.0), fov)                  # Scene.fs:36-43
         self.seed, self.jitter, self.lambertian_samples = int(seed), int(jitter), int(lambertian_samples)
         self.device, self.waves_per_cu, self.pool_blocks = int(device), int(waves_per_cu), int(pool_blocks)
+        self.estimator, self.bvh_ring, self.bvh_min_active = int(estimator), int(bvh_ring), int(bvh_min_active)
         self.frameBuffer = np.zeros((self.width, self.height, 4), dtype=np.float32)                  # Scene.fs:28
         self.depthBuffer = np.full((self.width, self.height), np.finfo(np.float32).max, dtype=np.float32)  # Scene.fs:29
         self.objectIds = np.zeros((self.width, self.height), dtype=np.uint64)
@@ -40,7 +42,8 @@ class Scene:
     def params(self, x_begin=0, x_end=None, x_step=1):
         return host.make_params(self.width, self.height, self.samplesPerPixel, self.maxTraceDepth,
                                 self.backgroundColor, self.jitter, self.seed, self.lambertian_samples,
-                                x_begin, x_end, x_step, self.waves_per_cu, self.pool_blocks)
+                                x_begin, x_end, x_step, self.waves_per_cu, self.pool_blocks,
+                                self.estimator, self.bvh_ring, self.bvh_min_active)
 
     def upload(self):
         """Flatten the surfaces and upload them once to HBM (rt_scene_create)."""
@@ -95,6 +98,21 @@ class Scene:
         abi.check(self._lib, self._lib.rt_render_device(self._scene, C.byref(self.camera), C.byref(p),
                                                         C.c_void_p(stream or 0), C.c_void_p(d_rgba), C.c_void_p(d_depth),
                                                         C.c_void_p(d_ids or 0), C.c_void_p(d_stats or 0)))
+
+    def renderSceneMulti(self, others=()):
+        """Scene.renderScene on several GPUs from one host thread (rt_render_multi): `self` is the root (its device
+        holds the gathered frame, its buffers receive it), `others` are Scenes with the same surfaces on other
+        devices (or on the same one: the partition does not care).  Share i renders the columns i, i+n, ..."""
+        scenes = [self] + list(others)
+        for s in scenes:
+            s.upload()
+        arr = (C.c_void_p * len(scenes))(*[s._scene for s in scenes])
+        p = self.params()
+        md, rays = C.c_float(0.0), C.c_uint64(0)
+        abi.check(self._lib, self._lib.rt_render_multi(arr, len(scenes), C.byref(self.camera), C.byref(p),
+                                                       self.frameBuffer.ctypes.data, self.depthBuffer.ctypes.data,
+                                                       self.objectIds.ctypes.data, C.byref(md), C.byref(rays)))
+        self.maxFrameBufferDepth, self.rayCount = md.value, rays.value
 
     def status(self):
         self.upload()

@@ -44,6 +44,11 @@ def load():
     lib.rto_generate_samples.argtypes = [P(abi.rt_surface), P(C.c_float), P(C.c_float), C.c_float,
                                          C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_float)]
     lib.rto_generate_samples.restype = C.c_int
+    lib.rto_generate_samples_single_path.argtypes = [P(abi.rt_surface), P(C.c_float), P(C.c_float), C.c_float,
+                                                     C.c_uint64, C.c_uint64, C.c_uint64, P(C.c_float), P(C.c_float)]
+    lib.rto_generate_samples_single_path.restype = C.c_int
+    lib.rto_random_float.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.rto_random_float.restype = C.c_float
     lib.rto_find_closest.argtypes = [P(abi.rt_surface), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rto_find_closest.restype = None
     lib.rto_set_raymap.argtypes = [C.c_void_p]
@@ -108,3 +113,12 @@ def generate_samples(surface, o, d, t, seed=1, ps=0, node=0):
     dirs, sh = (C.c_float * 12)(), (C.c_float * 12)()
     n = lib.rto_generate_samples(C.byref(s), f3(o), f3(d), t, seed, ps, node, dirs, sh)
     return n, np.array(dirs[:3 * n], dtype=np.float32).reshape(n, 3), np.array(sh[:3 * n], dtype=np.float32).reshape(n, 3)
+
+
+def generate_samples_single_path(surface, o, d, t, seed=1, ps=0, node=0):
+    """Surface.GenerateSamples under RT_ESTIMATOR_SINGLE_PATH. Returns (n, dir[3], shading[3])."""
+    lib = load()
+    s = surface.flatten() if isinstance(surface, host.Surface) else surface
+    dr, sh = (C.c_float * 3)(), (C.c_float * 3)()
+    n = lib.rto_generate_samples_single_path(C.byref(s), f3(o), f3(d), t, seed, ps, node, dr, sh)
+    return n, np.array(dr[:], dtype=np.float32), np.array(sh[:], dtype=np.float32)

@@ -21,9 +21,10 @@ def _declared_functions():
 
 
 def test_header_compiles_as_c_and_layouts_match_ctypes():
-    src = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%d %%d\\n",' \
+    src = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%d %%d %%zu %%zu\\n",' \
           'sizeof(rt_surface),sizeof(rt_camera),sizeof(rt_params),offsetof(rt_params,seed),offsetof(rt_params,x_begin),' \
-          'offsetof(rt_surface,g),offsetof(rt_params,pool_blocks),RT_ABI_VERSION,RT_STATS_WORDS);return 0;}\n' % HEADER
+          'offsetof(rt_surface,g),offsetof(rt_params,pool_blocks),RT_ABI_VERSION,RT_STATS_WORDS,' \
+          'offsetof(rt_params,estimator),offsetof(rt_params,reserved));return 0;}\n' % HEADER
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
@@ -31,8 +32,10 @@ def test_header_compiles_as_c_and_layouts_match_ctypes():
         out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
     got = [int(x) for x in out]
     want = [C.sizeof(abi.rt_surface), C.sizeof(abi.rt_camera), C.sizeof(abi.rt_params), abi.rt_params.seed.offset,
-            abi.rt_params.x_begin.offset, abi.rt_surface.g.offset, abi.rt_params.pool_blocks.offset, abi.RT_ABI_VERSION, 16]
+            abi.rt_params.x_begin.offset, abi.rt_surface.g.offset, abi.rt_params.pool_blocks.offset, abi.RT_ABI_VERSION, 16,
+            abi.rt_params.estimator.offset, abi.rt_params.reserved.offset]
     assert got == want
+    assert (got[0], got[1], got[2]) == (104, 80, 80)
     assert abi.surface_dtype.itemsize == C.sizeof(abi.rt_surface)
 
 
@@ -69,6 +72,7 @@ def test_argument_validation_messages():
     assert lib.rt_scene_create(None, 3, 0, None) == abi.RT_E_INVALID
     assert lib.rt_scene_status(None) == abi.RT_E_INVALID
     assert lib.rt_find_closest(None, 0, None, None, None, None) == abi.RT_E_INVALID
+    assert lib.rt_render_multi(None, 0, None, None, None, None, None, None, None) == abi.RT_E_INVALID
 
 
 def test_product_does_not_reference_the_oracle():

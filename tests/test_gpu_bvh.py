@@ -69,9 +69,11 @@ def test_ties_resolve_to_lowest_index():
     hit = idx >= 0
     assert hit.mean() > 0.5
 
-def test_deep_traversal_stack_spills_to_hbm():
+@pytest.mark.parametrize("ring", [0, 16])
+def test_deep_traversal_stack_spills_to_hbm(ring):
     """20 000 large spheres that all contain the camera: every box of the tree is hit, the per-lane stack grows to
-    3 x depth = 21 entries, past the 16-entry LDS ring, so the HBM backing store of rt_bvh.h is exercised."""
+    3 x depth = 21 entries — past the 8-entry LDS ring this tree size selects (ring 0) and past the 16-entry ring of
+    the large-tree variant (forced with bvh_ring), so the HBM backing store of rt_bvh.h is exercised in both."""
     rng = np.random.default_rng(11)
     n = 20000
     s = scenes.many_spheres(n, seed=4, environment=False)
@@ -80,7 +82,7 @@ def test_deep_traversal_stack_spills_to_hbm():
     s["g"][:, 3] = rng.uniform(6.0, 9.0, n).astype(np.float32)
     both = np.concatenate([s, scenes.reference_environment(1)])
     _compare(Scene(surfaces=both, width=40, height=30, samplesPerPixel=1, maxTraceDepth=2, jitter=1, seed=13,
-                   lambertian_samples=2, cameraOriginWS=(0.0, 0.0, 0.0), lookAt=(0.0, 0.0, -1.0)))
+                   lambertian_samples=2, cameraOriginWS=(0.0, 0.0, 0.0), lookAt=(0.0, 0.0, -1.0), bvh_ring=ring))
 
 
 def test_find_closest_100k_triangle_mesh():
@@ -186,3 +188,51 @@ def test_bvh_deep_branching_stays_within_the_pool_bound():
         assert np.array_equal(rgba, full[r::2])
         total += n
     assert total == rays
+
+
+def _frame_properties(s, first_hit_kw):
+    """Size-independent properties of a full-size frame: finite, alpha 1, status OK, deterministic, a 2-way column
+    partition bit-identical, primary visibility equal to the depth-0 render's."""
+    s.renderScene()
+    s.status()
+    full, depth, ids, rays, md = s.frameBuffer.copy(), s.depthBuffer.copy(), s.objectIds.copy(), s.rayCount, s.maxFrameBufferDepth
+    assert np.isfinite(full).all() and np.all(full[:, :, 3] == 1.0) and (full[:, :, :3] >= 0).all()
+    hit = ids != 0
+    assert np.all(depth[~hit] == np.finfo(np.float32).max) and depth[hit].max() == md
+    tot = 0
+    for r in range(2):
+        rgba, d, i, m, n = s.renderColumns(r, s.width, 2)
+        assert np.array_equal(rgba, full[r::2]) and np.array_equal(d, depth[r::2]) and np.array_equal(i, ids[r::2])
+        tot += n
+    assert tot == rays
+    one = Scene(**first_hit_kw)
+    one.renderScene()
+    assert np.array_equal(one.objectIds, ids) and np.array_equal(one.depthBuffer, depth)
+    return full, ids, rays
+
+
+def test_c4_mixed_4k_frame_properties():
+    """configs[3] at full size: scene_spheres + the 100 352-triangle mesh, 3840x2160 (4 spp here: the 64-spp frame is
+    the bench's; every property below is independent of the sample count)."""
+    m = np.concatenate([_records(SD.scene_spheres), scenes.heightfield_mesh(224, environment=False, base=-5.9, amplitude=1.2)])
+    kw = dict(surfaces=m, width=3840, height=2160, maxTraceDepth=5, jitter=1, seed=1)
+    full, ids, rays = _frame_properties(Scene(samplesPerPixel=4, **kw), dict(kw, samplesPerPixel=1, maxTraceDepth=0))
+    assert (ids >= 1000).mean() > 0.15 and {20, 24, 35, 1}.issubset(set(np.unique(ids).tolist()))
+    lights = np.isin(ids, [1, 2])
+    assert lights.any() and np.all(full[lights][:, :3] == 1.0)          # emitters seen directly are exactly white
+    assert 3840 * 2160 * 4 <= rays <= 3840 * 2160 * 4 * 5461
+
+
+def test_c5_one_million_spheres_frame_properties():
+    """configs[4] at full size: 1M spheres, 1920x1080, 4 spp, 16 bounces, Lambertian SampleCount 1 — the frame the
+    bench times, through the 16-entry-ring / 64-slot / 64-bit-node kernel."""
+    m = scenes.many_spheres(1_000_000)
+    kw = dict(surfaces=m, width=1920, height=1080, maxTraceDepth=16, jitter=1, seed=1, lambertian_samples=1,
+              **scenes.MANY_SPHERES_CAMERA)
+    full, ids, rays = _frame_properties(Scene(samplesPerPixel=4, **kw), dict(kw, samplesPerPixel=1, maxTraceDepth=0))
+    assert (ids >= 1000).mean() > 0.5
+    assert 1920 * 1080 * 4 <= rays <= 1920 * 1080 * 4 * 2 ** 17
+    # the single-path estimator on the same frame: same primary visibility, at most 18 rays per path
+    sp = Scene(samplesPerPixel=4, estimator=abi.ESTIMATOR_SINGLE_PATH, **kw)
+    sp.renderScene()
+    assert np.array_equal(sp.objectIds, ids) and sp.rayCount <= 1920 * 1080 * 4 * 18 and np.isfinite(sp.frameBuffer).all()

@@ -200,8 +200,8 @@ def test_c2_full_size_partition_and_determinism():
     assert np.all(s.depthBuffer[~hit] == np.finfo(np.float32).max)
 
 
-def test_c4_4k_64spp_frame_properties():
-    """The 4K 64-spp frame of the metric: primary visibility equals that of the 1-spp pinhole-free frame
+def test_c4s_4k_64spp_sphere_scene_frame_properties():
+    """The 4K 64-spp frame of the sphere scene (bench workload c4s; the mixed scene of configs[3] is in test_gpu_bvh.py): primary visibility equals that of the 1-spp pinhole-free frame
     (jitter is per pixel, not per sample: Scene.fs:98-104), every pixel is finite with alpha 1, and the
     ray count is within the 4-ary bound."""
     s = Scene(width=3840, height=2160, samplesPerPixel=64, maxTraceDepth=5, jitter=1, seed=1)
@@ -226,7 +226,12 @@ def test_rccl_collectives_of_the_frame_gather():
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=dev)
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     try:
         s = Scene(width=64, height=48, samplesPerPixel=1, maxTraceDepth=3, jitter=0)
         s.renderScene()

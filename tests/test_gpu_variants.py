@@ -1,0 +1,105 @@
+"""Every kernel instantiation and guard the product can reach, held to the oracle: the large-tree BVH variant
+(16-entry stack ring, 64 sample slots — what a scene above 262144 primitives runs, i.e. BASELINE.json configs[4]),
+forced on small scenes through rt_params.bvh_ring and reached for real with 270 000 spheres; refill thresholds above
+the sample-slot count; plane-only scenes past the BVH threshold; radiance the fixed-point sums cannot hold."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_amd import abi, host, scenes
+from raytracer_amd.scene import Scene
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+SD = host.SceneDefinitions
+
+
+def _records(surfaces):
+    arr = host.flatten_surfaces(surfaces)
+    return np.frombuffer(bytes(arr), dtype=abi.surface_dtype, count=len(surfaces)).copy()
+
+
+def _mixed(n=16):
+    return np.concatenate([_records(SD.scene_spheres), scenes.heightfield_mesh(n, environment=False, base=-5.9, amplitude=1.0)])
+
+
+@pytest.mark.parametrize("ring", [8, 16])
+@pytest.mark.parametrize("depth,lamb", [(4, 0), (16, 1)])
+def test_bvh_ring_variants_match_oracle(ring, depth, lamb):
+    """trace_kernel<NODE64, true, RING> for both ring sizes and both node-index widths (depth 16 -> NODE64)."""
+    _compare(Scene(surfaces=_mixed(), width=96, height=72, samplesPerPixel=2, maxTraceDepth=depth, jitter=1, seed=31,
+                   lambertian_samples=lamb, bvh_ring=ring))
+
+
+@pytest.mark.parametrize("depth,lamb", [(3, 0), (16, 1)])
+def test_large_tree_selects_the_ring16_kernel_and_matches_the_bruteforce_oracle(depth, lamb):
+    """More than 262144 primitives: the library picks the 16-entry ring / 64-slot kernel by itself (the c5 bench path).
+    Tiny frame, the oracle scans all 270 000 spheres per ray."""
+    s = scenes.many_spheres(270_000, seed=5, environment=False)
+    s["g"][:, :3] *= np.float32(0.25)           # [-125,125] x [0,12.5] x [-250,0]
+    m = np.concatenate([s, scenes.reference_environment(1)])
+    w, h = (32, 24) if depth < 8 else (16, 12)      # (dielectric splits double per bounce: ~100 rays per pixel at depth 16)
+    _compare(Scene(surfaces=m, width=w, height=h, samplesPerPixel=1, maxTraceDepth=depth, jitter=1, seed=3,
+                   lambertian_samples=lamb, cameraOriginWS=(0.0, 20.0, 15.0), lookAt=(0.0, 2.0, -100.0)))
+
+
+@pytest.mark.parametrize("ring,min_active", [(8, 64), (8, 33), (16, 64), (8, 1)])
+def test_refill_threshold_above_the_sample_slots_makes_progress(ring, min_active):
+    """The small-tree variant has 32 sample slots; a refill threshold above that once hung a wave with an empty pool,
+    no free slot and too few walking lanes.  The early exit now needs an iteration that started a
+    ray; any threshold must terminate with the oracle's image."""
+    _compare(Scene(surfaces=_mixed(12), width=80, height=60, samplesPerPixel=2, maxTraceDepth=4, jitter=1, seed=8,
+                   bvh_ring=ring, bvh_min_active=min_active))
+
+
+def test_more_than_64_planes_and_nothing_else_is_scanned():
+    """65+ planes with no sphere or triangle: there is nothing to build a tree from; the scene must render through the
+    linear scan (it once started a traversal at node 0 of an empty tree)."""
+    rng = np.random.default_rng(5)
+    surf = []
+    for i in range(70):
+        n = rng.normal(size=3)
+        n[2] = abs(n[2]) + 0.3
+        nn = host.SurfaceNormal(*n)
+        c = np.array([rng.uniform(-8, 8), rng.uniform(-5, 6), rng.uniform(-30, -8)], dtype=np.float32)
+        d = -host.dot(nn, c)
+        mat = host.Material((int(rng.integers(40, 255)), int(rng.integers(40, 255)), int(rng.integers(40, 255))))
+        plane = host.Plane(host.NumericsPlane(nn, d), c, float(rng.uniform(1, 4)), float(rng.uniform(1, 4)))
+        surf.append(host.Lambertian(100 + i, plane, mat) if i % 3 else host.Metal(100 + i, plane, mat, 0.1))
+    surf += SD.planes_scene_2[:1] + SD.lights
+    s = Scene(surfaces=surf, width=96, height=72, samplesPerPixel=2, maxTraceDepth=3, jitter=1, seed=4)
+    _compare(s)
+    assert len(np.unique(s.objectIds)) > 20
+
+
+def test_negative_albedo_and_emission_follow_the_oracle():
+    """The ABI takes any albedo / emission; negative contributions (floor-based fixed point) must sum like the oracle's floats."""
+    surf = _records(SD.scene_spheres)
+    surf["albedo"][1] = (-0.5, 0.25, -1e-9)
+    surf["emission"][10] = (1.0, -0.25, 1e-10)
+    surf["emission"][0] = (-1e-10, -1e-10, 2e-10)
+    s = Scene(surfaces=surf, width=96, height=72, samplesPerPixel=4, maxTraceDepth=4, jitter=1, seed=6)
+    s.renderScene()
+    ref = O.render(s.surfaces, s.camera, s.params())
+    assert np.array_equal(s.objectIds, ref["ids"]) and s.rayCount == ref["rays"]
+    # sqrt of a negative mean is NaN on both sides (Vector3.SquareRoot, Scene.fs:114); gamma magnifies differences
+    # next to zero, so the linear means are compared, and a sum may change sign only within that tolerance
+    got, want = s.frameBuffer.astype(np.float64) ** 2, ref["rgba"].astype(np.float64) ** 2
+    both = ~np.isnan(got) & ~np.isnan(want)
+    assert np.max(np.abs(got[both] - want[both])) <= 1e-5
+    one = np.isnan(got) != np.isnan(want)
+    assert np.all(np.nan_to_num(got[one]) + np.nan_to_num(want[one]) <= 1e-5)
+    assert np.isnan(want).any() and both.mean() > 0.5
+
+
+@pytest.mark.parametrize("value", [3e9, float("inf"), float("nan")])
+def test_radiance_beyond_the_fixed_point_range_is_reported(value):
+    surf = _records(SD.scene_spheres)
+    surf["emission"][10] = (value, 1.0, 1.0)
+    s = Scene(surfaces=surf, width=48, height=36, samplesPerPixel=1, maxTraceDepth=2, jitter=0)
+    with pytest.raises(abi.RtError) as e:
+        s.renderScene()
+    assert e.value.code == abi.RT_E_RANGE and "2^31" in str(e.value)
+    # the handle stays usable
+    good = Scene(width=48, height=36, samplesPerPixel=1, maxTraceDepth=2, jitter=0)
+    _compare(good)
