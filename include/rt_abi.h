@@ -156,6 +156,21 @@ int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* pa
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);
 
+/* rt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  NO counterpart in the reference.  Same arguments, same results bit for bit, but everything
+ * the kernels need beyond the inputs and outputs — the per-pixel radiance sums, the record-pool spill area, the
+ * traversal-stack backing store — lives in one static device array of RT_NOALLOC_SCRATCH_BYTES per GPU (held from
+ * library load until the process ends) instead of buffers the scene grows with hipMalloc; the call performs no
+ * hipMalloc/hipFree.  Limits: at most RT_NOALLOC_MAX_PIXELS rendered pixels per call (ncols*height), else
+ * RT_E_UNSUPPORTED; the number of persistent waves shrinks until their spill areas fit (slower for deep traces, same
+ * image).  All calls on one GPU share that GPU's array: two calls that overlap in time on one GPU race — serialise
+ * them (one stream, or events).                                                                                    */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+#define RT_NOALLOC_MAX_PIXELS    (1 << 20)
+int  rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                              void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
+                              uint64_t* d_stats);
+
 /* `Scene.renderScene ()` (Scene.fs:117-121) on several GPUs of one node from ONE host thread:
  * scenes[i] (the same surfaces uploaded to any device, normally device i) renders the interleaved columns
  * i, i+n, ... of the whole frame on its own stream; each device then stores its block into the frame held in

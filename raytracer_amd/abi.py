@@ -23,6 +23,8 @@ GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
 RT_ABI_VERSION = 6
 RT_STATS_WORDS = 16
+RT_NOALLOC_SCRATCH_BYTES = 64 << 20
+RT_NOALLOC_MAX_PIXELS = 1 << 20
 
 
 class rt_surface(C.Structure):
@@ -94,6 +96,7 @@ ABI_SYMBOLS = (
     "rt_scene_create",
     "rt_render",
     "rt_render_device",
+    "rt_render_device_noalloc",
     "rt_render_multi",
     "rt_find_closest",
     "rt_scene_status",
@@ -125,6 +128,8 @@ def load_hip_library():
     lib.rt_render_device.argtypes = [C.c_void_p, P(rt_camera), P(rt_params), C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rt_render_device.restype = C.c_int
+    lib.rt_render_device_noalloc.argtypes = lib.rt_render_device.argtypes
+    lib.rt_render_device_noalloc.restype = C.c_int
     lib.rt_render_multi.argtypes = [P(C.c_void_p), C.c_int32, P(rt_camera), P(rt_params), C.c_void_p, C.c_void_p,
                                     C.c_void_p, P(C.c_float), P(C.c_uint64)]
     lib.rt_render_multi.restype = C.c_int

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -93,6 +94,35 @@ int default_samples(int kind, int sample_count, int lambertian_default)
 
 }  // namespace
 
+// ---- the allocation-free entry point's scratch (include/rt_abi.h rt_render_device_noalloc) ------------------
+// One array per GPU the library's code object is loaded on, held until the process ends.  `scratch` is a
+// host-side stand-in for the symbol, never a device address: the address on each device is looked up once
+// (scratch_of) and only that pointer is handed to kernels, memsets and copies.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = { nullptr };
+
+// Address of this device's copy of `scratch` (the device must be current).  Looked up once per device.
+int scratch_of(int device, unsigned char** out)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RT_E_UNSUPPORTED, "device %d beyond the %d this library tracks", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(RT_E_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = static_cast<unsigned char*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
+}  // namespace
+
 struct rt_scene {
     int device = 0;
     int64_t n = 0;
@@ -107,6 +137,7 @@ struct rt_scene {
     size_t spill_bytes = 0;
     uint32_t* d_gstack = nullptr;              // backing store of the BVH traversal stacks (grown on demand)
     size_t gstack_bytes = 0;
+    unsigned char* scratch = nullptr;          // this device's copy of the static scratch array (allocation-free entry)
     int num_cus = 0;
     int64_t nloose = 0;                        // entries of d_geom (all surfaces, or only the planes of a BVH scene)
     bool use_bvh = false;
@@ -158,6 +189,14 @@ BvhRef bvh_ref(const rt_scene* sc)
     return b;
 }
 
+// Where a launch keeps what is neither input nor output: the scene's own buffers, grown on demand (hipMalloc), or a
+// carve-up of the static scratch array (no allocation; the grid shrinks until its spill and stack areas fit).
+struct Workspace {
+    bool fixed = false;
+    unsigned char* base = nullptr;   // fixed: first free byte of the scratch array
+    size_t avail = 0;                // fixed: bytes from there to its end
+};
+
 // refill threshold of the BVH kernels (lanes still walking); a wave needs a free sample slot to start a primary ray,
 // so the default must not exceed the sample slots of any variant (the kernel makes progress either way, see
 // trace_kernel "leave early", but a larger value only costs occupancy of the lanes)
@@ -166,7 +205,7 @@ static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slo
 
 template <bool NODE64, bool BVH, int RING>
 int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_cu,
-                 size_t smem, hipStream_t stream)
+                 size_t smem, hipStream_t stream, const Workspace& ws)
 {
     const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING>);
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
@@ -192,14 +231,26 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
     if (grid * 3 > chunks * 2) grid = std::max<unsigned long long>(chunks * 2 / 3, 1ull);
     const size_t wave_spill = (size_t)a.max_spill * NF * 64 * sizeof(uint32_t);
     const size_t wave_stack = BVH ? (size_t)kBvhStack * 64 * sizeof(uint32_t) : 0;
-    int rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_spill), &sc->spill_bytes, (size_t)grid * wave_spill);
-    if (rc) return rc;
-    c.spill = sc->d_spill;
-    c.gstack = nullptr;
-    if (BVH) {
-        rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_gstack), &sc->gstack_bytes, (size_t)grid * wave_stack);
+    if (ws.fixed) {
+        // the image does not depend on the number of waves (integer sums): take as many as the scratch holds
+        const unsigned long long fit = ws.avail / (wave_spill + wave_stack);
+        const bool shrunk = fit < grid;
+        if (shrunk) grid = fit;
+        if (shrunk && grid < (unsigned long long)sc->num_cus)
+            return fail(RT_E_UNSUPPORTED, "the %zu-byte scratch of rt_render_device_noalloc cannot hold one wave per CU for this frame and trace depth",
+                        (size_t)RT_NOALLOC_SCRATCH_BYTES);
+        c.spill = reinterpret_cast<uint32_t*>(ws.base);
+        c.gstack = BVH ? reinterpret_cast<uint32_t*>(ws.base + (size_t)grid * wave_spill) : nullptr;
+    } else {
+        int rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_spill), &sc->spill_bytes, (size_t)grid * wave_spill);
         if (rc) return rc;
-        c.gstack = sc->d_gstack;
+        c.spill = sc->d_spill;
+        c.gstack = nullptr;
+        if (BVH) {
+            rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_gstack), &sc->gstack_bytes, (size_t)grid * wave_stack);
+            if (rc) return rc;
+            c.gstack = sc->d_gstack;
+        }
     }
     hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
                        bvh_ref(sc));
@@ -215,9 +266,9 @@ constexpr int64_t kBvhSmallTree = 262144;
 
 int columns_of(const rt_params* p) { return (p->x_end - p->x_begin + p->x_step - 1) / p->x_step; }
 
-// The render behind rt_render_device: memsets, trace_kernel, resolve_kernel on `stream`.
+// The render behind rt_render_device and rt_render_device_noalloc: memsets, trace_kernel, resolve_kernel on `stream`.
 int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hipStream_t stream,
-                     float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats)
+                     float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats, bool noalloc)
 {
     if (!sc) return fail(RT_E_INVALID, "scene is null");
     int rc = check_params(cam, p);
@@ -230,9 +281,21 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     const long long npix = (long long)ncols * p->height;
     if (npix > 0x7fffffffLL) return fail(RT_E_INVALID, "frame too large for one launch");
     const size_t accum_bytes = (size_t)npix * 4 * sizeof(unsigned long long);
-    int rc2 = ensure_buffer(reinterpret_cast<void**>(&sc->d_accum), &sc->accum_bytes, accum_bytes);
-    if (rc2) return rc2;
-    unsigned long long* accum = sc->d_accum;
+    Workspace ws;
+    unsigned long long* accum = nullptr;
+    if (noalloc) {
+        if (npix > (long long)RT_NOALLOC_MAX_PIXELS)
+            return fail(RT_E_UNSUPPORTED, "rt_render_device_noalloc renders at most %d pixels per call (%lld asked): use rt_render_device",
+                        RT_NOALLOC_MAX_PIXELS, npix);
+        if (!sc->scratch) return fail(RT_E_HIP, "the scratch array was not located on device %d", sc->device);
+        accum = reinterpret_cast<unsigned long long*>(sc->scratch);
+        const size_t used = (accum_bytes + 255) & ~(size_t)255;
+        ws.fixed = true; ws.base = sc->scratch + used; ws.avail = (size_t)RT_NOALLOC_SCRATCH_BYTES - used;
+    } else {
+        rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_accum), &sc->accum_bytes, accum_bytes);
+        if (rc) return rc;
+        accum = sc->d_accum;
+    }
 
     RenderArgs a; memset(&a, 0, sizeof a);
     ColdArgs c; memset(&c, 0, sizeof c);
@@ -294,13 +357,13 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     HIP_TRY(hipMemsetAsync(accum, 0, accum_bytes, stream));
     if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
     if (sc->use_bvh)
-        rc = ring == 8 ? (node64 ? launch_trace<true, true, 8>(sc, c, a, p->waves_per_cu, smem, stream)
-                                 : launch_trace<false, true, 8>(sc, c, a, p->waves_per_cu, smem, stream))
-                       : (node64 ? launch_trace<true, true, 16>(sc, c, a, p->waves_per_cu, smem, stream)
-                                 : launch_trace<false, true, 16>(sc, c, a, p->waves_per_cu, smem, stream));
+        rc = ring == 8 ? (node64 ? launch_trace<true, true, 8>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                 : launch_trace<false, true, 8>(sc, c, a, p->waves_per_cu, smem, stream, ws))
+                       : (node64 ? launch_trace<true, true, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                 : launch_trace<false, true, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws));
     else
-        rc = node64 ? launch_trace<true, false, 16>(sc, c, a, p->waves_per_cu, smem, stream)
-                    : launch_trace<false, false, 16>(sc, c, a, p->waves_per_cu, smem, stream);
+        rc = node64 ? launch_trace<true, false, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                    : launch_trace<false, false, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws);
     if (rc) return rc;
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, accum, d_rgba,
                        npix, p->spp);
@@ -340,7 +403,7 @@ int render_staged(rt_scene* sc, const rt_camera* cam, const rt_params* p, size_t
     int rc = staging_of(sc, npix, st);
     if (rc) return rc;
     for (int attempt = 0;; attempt++) {
-        rc = render_on_stream(sc, cam, p, sc->stream, st->rgba, st->depth, want_ids ? st->ids : nullptr, st->stats);
+        rc = render_on_stream(sc, cam, p, sc->stream, st->rgba, st->depth, want_ids ? st->ids : nullptr, st->stats, false);
         if (rc) return rc;
         rc = status_after(sc, sc->stream, nullptr);
         if (rc != RT_E_OVERFLOW || !sc->use_bvh || attempt >= 3) return rc;
@@ -502,6 +565,9 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
         rt_scene_destroy(sc);
         return fail(RT_E_HIP, "scene upload: %s", hipGetErrorString(e));
     }
+    // set-up of the allocation-free entry point: this device's address of the static scratch array, once per device
+    const int rc = scratch_of(device, &sc->scratch);
+    if (rc) { rt_scene_destroy(sc); return rc; }
     *out = sc;
     g_err[0] = 0;
     return RT_OK;
@@ -529,7 +595,13 @@ void rt_scene_destroy(rt_scene* sc)
 int rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_params* p, void* stream_v,
                      float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats)
 {
-    return render_on_stream(sc, cam, p, static_cast<hipStream_t>(stream_v), d_rgba, d_depth, d_object_id, d_stats);
+    return render_on_stream(sc, cam, p, static_cast<hipStream_t>(stream_v), d_rgba, d_depth, d_object_id, d_stats, false);
+}
+
+int rt_render_device_noalloc(rt_scene* sc, const rt_camera* cam, const rt_params* p, void* stream_v,
+                             float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats)
+{
+    return render_on_stream(sc, cam, p, static_cast<hipStream_t>(stream_v), d_rgba, d_depth, d_object_id, d_stats, true);
 }
 
 int rt_scene_status(rt_scene* sc)
@@ -617,7 +689,7 @@ int rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* c
         rc = staging_of(sc, npix, &st[(size_t)i]);
         if (rc) return rc;
         rc = render_on_stream(sc, cam, &pi, sc->stream, st[(size_t)i].rgba, st[(size_t)i].depth, object_id ? st[(size_t)i].ids : nullptr,
-                              st[(size_t)i].stats);
+                              st[(size_t)i].stats, false);
         if (rc) return rc;
         const long long quads = (long long)npix;
         hipLaunchKernelGGL(place_columns_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, sc->stream,

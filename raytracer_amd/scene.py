@@ -99,6 +99,16 @@ class Scene:
                                                         C.c_void_p(stream or 0), C.c_void_p(d_rgba), C.c_void_p(d_depth),
                                                         C.c_void_p(d_ids or 0), C.c_void_p(d_stats or 0)))
 
+    def renderColumnsDeviceNoAlloc(self, d_rgba, d_depth, d_ids=None, d_stats=None, stream=None,
+                                   x_begin=0, x_end=None, x_step=1):
+        """`renderColumnsDevice` through rt_render_device_noalloc: same results, no hipMalloc inside the call
+        (static per-GPU scratch; at most abi.RT_NOALLOC_MAX_PIXELS pixels)."""
+        self.upload()
+        p = self.params(x_begin, x_end, x_step)
+        abi.check(self._lib, self._lib.rt_render_device_noalloc(self._scene, C.byref(self.camera), C.byref(p),
+                                                                C.c_void_p(stream or 0), C.c_void_p(d_rgba), C.c_void_p(d_depth),
+                                                                C.c_void_p(d_ids or 0), C.c_void_p(d_stats or 0)))
+
     def renderSceneMulti(self, others=()):
         """Scene.renderScene on several GPUs from one host thread (rt_render_multi): `self` is the root (its device
         holds the gathered frame, its buffers receive it), `others` are Scenes with the same surfaces on other

@@ -21,10 +21,10 @@ def _declared_functions():
 
 
 def test_header_compiles_as_c_and_layouts_match_ctypes():
-    src = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%d %%d %%zu %%zu\\n",' \
+    src = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%d %%d %%zu %%zu %%u %%d\\n",' \
           'sizeof(rt_surface),sizeof(rt_camera),sizeof(rt_params),offsetof(rt_params,seed),offsetof(rt_params,x_begin),' \
           'offsetof(rt_surface,g),offsetof(rt_params,pool_blocks),RT_ABI_VERSION,RT_STATS_WORDS,' \
-          'offsetof(rt_params,estimator),offsetof(rt_params,reserved));return 0;}\n' % HEADER
+          'offsetof(rt_params,estimator),offsetof(rt_params,reserved),RT_NOALLOC_SCRATCH_BYTES,RT_NOALLOC_MAX_PIXELS);return 0;}\n' % HEADER
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
@@ -33,7 +33,7 @@ def test_header_compiles_as_c_and_layouts_match_ctypes():
     got = [int(x) for x in out]
     want = [C.sizeof(abi.rt_surface), C.sizeof(abi.rt_camera), C.sizeof(abi.rt_params), abi.rt_params.seed.offset,
             abi.rt_params.x_begin.offset, abi.rt_surface.g.offset, abi.rt_params.pool_blocks.offset, abi.RT_ABI_VERSION, 16,
-            abi.rt_params.estimator.offset, abi.rt_params.reserved.offset]
+            abi.rt_params.estimator.offset, abi.rt_params.reserved.offset, abi.RT_NOALLOC_SCRATCH_BYTES, abi.RT_NOALLOC_MAX_PIXELS]
     assert got == want
     assert (got[0], got[1], got[2]) == (104, 80, 80)
     assert abi.surface_dtype.itemsize == C.sizeof(abi.rt_surface)
@@ -73,6 +73,7 @@ def test_argument_validation_messages():
     assert lib.rt_scene_status(None) == abi.RT_E_INVALID
     assert lib.rt_find_closest(None, 0, None, None, None, None) == abi.RT_E_INVALID
     assert lib.rt_render_multi(None, 0, None, None, None, None, None, None, None) == abi.RT_E_INVALID
+    assert lib.rt_render_device_noalloc(None, None, None, None, None, None, None, None) == abi.RT_E_INVALID
 
 
 def test_product_does_not_reference_the_oracle():
