@@ -674,7 +674,7 @@ int rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* c
         rt_scene* sc = scenes[i];
         rt_params pi = *p;
         pi.x_begin = i; pi.x_step = nscenes;
-        ncols[(size_t)i] = i < W ? columns_of(&pi) : 0;
+        ncols[(size_t)i] = share_columns(W, i, nscenes);
         if (ncols[(size_t)i] <= 0) continue;
         HIP_TRY(hipSetDevice(sc->device));
         if (sc->device != root->device) {

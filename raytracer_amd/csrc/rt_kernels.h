@@ -24,6 +24,7 @@
 #pragma once
 #include "rt_bvh.h"
 #include "rt_device.h"
+#include "rt_partition.h"
 
 namespace rt {
 
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256) void place_columns_kernel(const float* __restr
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= (long long)ncols * H) return;
     const int k = (int)(o / H), py = (int)(o - (long long)k * H);
-    const long long dst = (long long)(r + k * n) * H + py;
+    const long long dst = frame_index(r, n, k, H, py);
     *reinterpret_cast<float4*>(f_rgba + 4 * dst) = *reinterpret_cast<const float4*>(rgba + 4 * o);
     f_depth[dst] = depth[o];
     if (ids) f_ids[dst] = ids[o];

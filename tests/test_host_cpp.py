@@ -55,3 +55,16 @@ def test_cpp_render_scene_matches_python_scene(tmp_path):
     s.renderScene()
     assert np.array_equal(fb, s.frameBuffer) and np.array_equal(db, s.depthBuffer) and np.array_equal(ids, s.objectIds)
     assert md == np.float32(s.maxFrameBufferDepth) and int(rays) == s.rayCount
+
+
+def test_multi_gpu_placement_arithmetic():
+    """rt_partition.h (used by rt_render_multi and its placement kernel) compiled for the host: every share's compact
+    elements cover the frame exactly once, and the Python partition of bench.py (multi.columns_of_rank) agrees."""
+    out = subprocess.run([_build("partition_check")], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("ok ")
+    from raytracer_amd import multi
+    for width in (1, 5, 101, 3840):
+        for world in (1, 3, 8):
+            for r in range(world):
+                xb, xe, xs, ncols = multi.columns_of_rank(width, r, world)
+                assert (xb, xs) == (r, world) and ncols == len(range(r, width, world))

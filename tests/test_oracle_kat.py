@@ -240,3 +240,61 @@ def test_triangle_known_answers():
     assert has and not acc and abs(t - 0.0005) < 1e-6
     has, t, acc = O.intersect(tri, (0.25, 0.25, 0.0), (0.0, 0.0, 1.0))   # pointing away: t = -2, not acceptable
     assert has and not acc and t == -2.0
+
+
+# ---- single-path estimator (Dielectric.Scatter, Surface.fs:155-166; notes.txt:21-54) ------------
+def test_single_path_dielectric_scatter_picks_reflection_with_probability_F():
+    """Normal incidence, ior 1.5: reflectProb = 0.04.  Scatter reflects when RandomFloat <= reflectProb, else
+    refracts; either way shading = BRDF * (1/PDF) = Albedo (Surface.fs:28,35-36,162,166)."""
+    lib = O.load()
+    s = Dielectric(1, Sphere((0.0, 0.0, -5.0), 1.0), Material(Rgba32.AntiqueWhite), 1.5)
+    alb = host.Rgba32.to_vector3(Rgba32.AntiqueWhite)
+    nrefl = 0
+    trials = 20000
+    for ps in range(trials):
+        n, d, sh = O.generate_samples_single_path(s, (0, 0, 0), (0, 0, -1), 4.0, seed=11, ps=ps, node=0)
+        assert n == 1 and np.array_equal(sh, alb)
+        u = lib.rto_random_float(11, ps, 1)                   # the draw is keyed by the child node 4*0+1
+        assert 0.0 <= u < 1.0
+        if u <= np.float32(0.04):
+            nrefl += 1
+            assert np.allclose(d, (0, 0, 1), atol=1e-6)
+        else:
+            assert np.allclose(d, (0, 0, -1), atol=1e-6)
+    assert abs(nrefl / trials - 0.04) < 0.005
+
+
+def test_single_path_total_internal_reflection_never_refracts():
+    s = Dielectric(1, Sphere((0.0, 0.0, 0.0), 1.0), Material(Rgba32.White), 1.5)
+    o = np.array([0.0, 0.9, 0.0], dtype=np.float32)
+    d = np.array([1.0, 0.0, 0.0], dtype=np.float32)
+    _, t, ok = O.intersect(s, o, d)
+    assert ok
+    _, dirs, _ = O.generate_samples(s, o, d, t)               # branching: the single reflected sample
+    for ps in range(200):
+        n, dr, sh = O.generate_samples_single_path(s, o, d, t, seed=2, ps=ps)
+        assert n == 1 and np.array_equal(dr, dirs[0]) and np.allclose(sh, 1.0)
+
+
+def test_single_path_lambertian_and_metal_are_the_first_branching_sample():
+    """One child per hit through the default GenerateSamples with SampleCount 1: child node 4k+1, i.e. exactly sample 0
+    of the branching estimator, with the same shading (the division by the sample count happens in rayTrace)."""
+    for s in (Lambertian(1, Sphere((0.0, 0.0, -5.0), 1.0), Material(Rgba32.RoyalBlue)),
+              Metal(2, Sphere((0.0, 0.0, -5.0), 1.0), Material(Rgba32.White), 0.4)):
+        n4, dirs, sh4 = O.generate_samples(s, (0, 0, 0), (0, 0, -1), 4.0, seed=3, ps=17, node=5)
+        n1, d1, sh1 = O.generate_samples_single_path(s, (0, 0, 0), (0, 0, -1), 4.0, seed=3, ps=17, node=5)
+        assert n1 == 1 and n4 >= 1 and np.array_equal(d1, dirs[0]) and np.array_equal(sh1, sh4[0])
+    light = NoSurface(1, Sphere((0.0, 0.0, -5.0), 1.0), Material(Rgba32.White, 0.0, Rgba32.White, 1.0))
+    assert O.generate_samples_single_path(light, (0, 0, 0), (0, 0, -1), 4.0)[0] == 0
+
+
+def test_single_path_render_has_one_ray_per_level_and_the_same_mean():
+    """A path intersects at most maxTraceDepth + 2 rays; its expectation is the branching estimator's (checked
+    loosely on the frame mean here, to 45 dB on the GPU in tests/test_gpu_estimator.py)."""
+    cam = host.make_camera()
+    sc = host.SceneDefinitions.scene_spheres
+    a = O.render(sc, cam, host.make_params(40, 30, 256, 4, jitter=0, seed=5, estimator=1))
+    b = O.render(sc, cam, host.make_params(40, 30, 16, 4, jitter=0, seed=6))
+    assert a["rays"] <= 40 * 30 * 256 * 6 and np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["depth"], b["depth"])
+    la, lb = a["rgba"][:, :, :3].astype(np.float64) ** 2, b["rgba"][:, :, :3].astype(np.float64) ** 2
+    assert abs(la.mean() - lb.mean()) < 0.01 * lb.mean() + 1e-3
