@@ -184,6 +184,7 @@ def main():
         diag["nodes"], diag["prims"] = int(st[8].item()), int(st[9].item())
         diag["rounds_inner"], diag["rounds_leaf"] = int(st[10].item()), int(st[11].item())
         diag["phase_clk"] = [int(st[i].item()) for i in (12, 13, 14, 15)]
+        diag["max_wave_clk"] = int(st[18].item())
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
         return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
 
@@ -237,7 +238,7 @@ def main():
                                   "phase_clk_gen_scan_trav_shade": diag["phase_clk"]}
                                  if args.workload in BVH_COST else None),
                          "lane_fill": diag["rays"] / max(1, diag["iters"] * 64), "waves": diag["waves"],
-                         "mean_wave_clk": diag["sum_wave_clk"] / max(1, diag["waves"])},
+                         "mean_wave_clk": diag["sum_wave_clk"] / max(1, diag["waves"]), "max_wave_clk": diag["max_wave_clk"]},
         }
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}

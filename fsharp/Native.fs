@@ -52,7 +52,7 @@ type RtParams =
     val mutable estimator : int32       // 0 = renderScene's branching estimator, 1 = single path (Dielectric.Scatter)
     val mutable bvhRing : int32
     val mutable bvhMinActive : int32
-    val mutable reserved : int32
+    val mutable twoPass : int32
 
 [<Literal>]
 let RtAbiVersion = 6

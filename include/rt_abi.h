@@ -111,7 +111,9 @@ typedef struct rt_params {
     int32_t  bvh_ring;            /* tuning/testing: traversal-stack entries kept in LDS, 0 = by tree size, 8 or 16
                                      (selects the kernel variant a BVH scene runs; results do not depend on it)   */
     int32_t  bvh_min_active;      /* tuning/testing: lanes still walking below which a wave refills; 0 = 28, 1..64 */
-    int32_t  reserved;            /* must be 0                                                                    */
+    int32_t  two_pass;            /* tuning/testing: 0 = frames of at most 2^21 pixel-samples are rendered in two passes
+                                     (primaries, then their subtrees shared among all waves), 1 = always one pass;
+                                     the image does not depend on it                                                 */
 } rt_params;
 
 /* Estimators.  BRANCHING is what Scene.rayTrace computes (Scene.fs:51-72): every hit spawns SampleCount children
@@ -149,9 +151,10 @@ int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
  * [6] summed wave lifetimes in shader clocks, [7] waves, [8] BVH nodes visited, [9] BVH primitives
  * tested (0 for linear-scan scenes), [10] / [11] BVH traversal rounds with an inner-node / a leaf step,
  * [12..15] shader clocks summed over waves in the phases generate / plane scan / BVH traversal / shade+flush
- * (BVH scenes only, filled by builds with -DRT_PHASE_TIMING, else 0); may be NULL.
+ * (filled by builds with -DRT_PHASE_TIMING, else 0), [16], [17] unused, [18] the longest wave lifetime in shader clocks
+ * ([6] / [7] is the mean), [19] unused; may be NULL.
  * No counterpart in the reference.                                                            */
-#define RT_STATS_WORDS 16
+#define RT_STATS_WORDS 20
 int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                       void* stream, float* d_rgba, float* d_depth, uint64_t* d_object_id,
                       uint64_t* d_stats);

@@ -22,7 +22,7 @@ KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
 RT_ABI_VERSION = 6
-RT_STATS_WORDS = 16
+RT_STATS_WORDS = 20
 RT_NOALLOC_SCRATCH_BYTES = 64 << 20
 RT_NOALLOC_MAX_PIXELS = 1 << 20
 
@@ -67,7 +67,7 @@ class rt_params(C.Structure):
         ("estimator", C.c_int32),
         ("bvh_ring", C.c_int32),
         ("bvh_min_active", C.c_int32),
-        ("reserved", C.c_int32),
+        ("two_pass", C.c_int32),
     ]
 
 

@@ -18,9 +18,11 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 using namespace rt;
+static_assert(kStatsWords == RT_STATS_WORDS, "statistics words");
 
 namespace {
 
@@ -130,6 +132,7 @@ struct rt_scene {
     GeomRec* d_geom = nullptr;
     ShadeRec* d_shade = nullptr;
     int* d_status = nullptr;
+    unsigned long long* d_statpart = nullptr;  // kStatsParts partial statistics arrays (folded by stats_reduce_kernel)
     unsigned long long* d_counter = nullptr;   // work counter of the persistent waves
     unsigned long long* d_accum = nullptr;     // per-pixel 32.32 radiance sums (grown on demand)
     size_t accum_bytes = 0;
@@ -145,8 +148,10 @@ struct rt_scene {
     float4* d_nodes = nullptr; float4* d_pdata = nullptr;
     int nnodes = 0, bvh_depth = 0;
     int64_t nprims = 0;                        // primitives in the BVH
-    int occ_smem[4] = { -1, -1, -1, -1 };      // LDS size the cached occupancy below was queried for (per kernel variant)
-    int occ_per_cu[4] = { 0, 0, 0, 0 };
+    int occ_smem[12] = { -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1 };   // LDS size the cached occupancy below was queried for (per kernel variant)
+    int occ_per_cu[12] = { 0 };
+    unsigned char* d_list = nullptr;    // small frames: hit records of the primary pass (grown on demand)
+    size_t list_bytes = 0;
     float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
     size_t tmp_bytes = 0;
     float* d_frame = nullptr;           // rt_render_multi: the gathered frame on the root scene's device
@@ -178,7 +183,7 @@ int check_params(const rt_camera* cam, const rt_params* p)
     if (p->estimator != RT_ESTIMATOR_BRANCHING && p->estimator != RT_ESTIMATOR_SINGLE_PATH) return fail(RT_E_INVALID, "estimator must be 0 or 1");
     if (p->bvh_ring != 0 && p->bvh_ring != 8 && p->bvh_ring != 16) return fail(RT_E_INVALID, "bvh_ring must be 0, 8 or 16");
     if (p->bvh_min_active < 0 || p->bvh_min_active > 64) return fail(RT_E_INVALID, "bvh_min_active must be in 0..64");
-    if (p->reserved != 0) return fail(RT_E_INVALID, "reserved must be 0");
+    if (p->two_pass != 0 && p->two_pass != 1) return fail(RT_E_INVALID, "two_pass must be 0 (automatic) or 1 (off)");
     return RT_OK;
 }
 
@@ -203,14 +208,16 @@ struct Workspace {
 constexpr int kMinActiveDefault = 28;
 static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slots_of(true, 16), "refill threshold above the sample slots");
 
-template <bool NODE64, bool BVH, int RING>
+// PHASE: 0 = one launch per frame; 1, 2 = the two passes of a small frame (trace_kernel)
+template <bool NODE64, bool BVH, int RING, int PHASE>
 int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_cu,
                  size_t smem, hipStream_t stream, const Workspace& ws)
 {
-    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING>);
+    constexpr int phase = PHASE;
+    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING, PHASE>);
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     // the attribute and the occupancy query cost host time: once per (kernel, LDS size) and scene
-    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0);
+    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE;
     int& cached_smem = sc->occ_smem[variant];
     int& cached_per_cu = sc->occ_per_cu[variant];
     if (cached_smem != (int)smem) {
@@ -225,10 +232,16 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
     // persistent waves: no more than fit on the chip, no more than there are 64-sample refills
     const unsigned long long chunks = (c.total + 63) / 64;
     unsigned long long grid = (unsigned long long)per_cu * (unsigned long long)sc->num_cus;
-    // Small frames (640x480x1 has 4800 refills for 4864 resident waves): with one refill per wave there is no
-    // dynamic balancing left and the waves that drew expensive pixels finish alone (measured: mean wave lifetime
-    // 0.59 ms of a 1.13 ms kernel).  Two thirds as many waves as refills balances better: 13.8 -> 15.0 Grays/s.
-    if (grid * 3 > chunks * 2) grid = std::max<unsigned long long>(chunks * 2 / 3, 1ull);
+    if (phase == 0) {
+        // Frames that are small for the chip but too large for the two-pass scheme: with one refill per wave there is
+        // no dynamic balancing left and the waves that drew expensive pixels finish alone.  Two thirds as many waves
+        // as refills balances better (measured on 640x480x1 before it became a two-pass frame: 13.8 -> 15.0 Grays/s).
+        if (grid * 3 > chunks * 2) grid = std::max<unsigned long long>(chunks * 2 / 3, 1ull);
+    } else {
+        // a pass hands out 32 pixel-samples (1) or 32 list entries (2) at a time: no more waves than hand-outs
+        const unsigned long long handouts = phase == 1 ? (c.total + 31) / 32 : (4 * c.total + 31) / 32;
+        if (grid > handouts) grid = std::max<unsigned long long>(handouts, 1ull);
+    }
     const size_t wave_spill = (size_t)a.max_spill * NF * 64 * sizeof(uint32_t);
     const size_t wave_stack = BVH ? (size_t)kBvhStack * 64 * sizeof(uint32_t) : 0;
     if (ws.fixed) {
@@ -252,7 +265,7 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
             c.gstack = sc->d_gstack;
         }
     }
-    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
+    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING, PHASE>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
                        bvh_ref(sc));
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -263,6 +276,9 @@ constexpr int64_t kBvhThreshold = 64;
 constexpr int64_t kLooseSpheres = 16;
 // Up to this many primitives the 8-entry stack ring is used (measured: 100k triangles +2..10 %, 1M spheres -11 %).
 constexpr int64_t kBvhSmallTree = 262144;
+// Frames of at most this many pixel-samples are rendered in two passes (render_on_stream); the list of primary hit
+// records takes up to 4 x 64 bytes per pixel-sample.
+constexpr unsigned long long kTwoPassMaxSamples = 1ull << 19;
 
 int columns_of(const rt_params* p) { return (p->x_end - p->x_begin + p->x_step - 1) / p->x_step; }
 
@@ -301,7 +317,7 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     ColdArgs c; memset(&c, 0, sizeof c);
     c.accum = accum; c.counter = sc->d_counter; c.depth = d_depth;
     c.ids = reinterpret_cast<unsigned long long*>(d_object_id);
-    c.stats = reinterpret_cast<unsigned long long*>(d_stats);
+    c.stats = d_stats ? sc->d_statpart : nullptr;
     c.status = sc->d_status;
     c.total = (unsigned long long)npix * (unsigned long long)p->spp;
     c.npix = (unsigned int)npix;
@@ -319,6 +335,9 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     a.lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
     a.estimator = p->estimator;
+    // second pass of a small frame: 32 list entries at a time, taken when the pool holds at most 16 records (measured on
+    // 640x480x1: chunks of 8 / 16 entries 2.0 / 1.2 ms, thresholds 0 / 48 records 0.83 / 1.09 ms against 0.83 ms)
+    a.list_chunk = kListChunk; a.list_low = 16;
     // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
     // 28 of its lanes still walk the tree; a group of lanes steps once 16 of them have gathered
     a.min_active = p->bvh_min_active > 0 ? p->bvh_min_active : kMinActiveDefault;
@@ -333,7 +352,8 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     // A BVH scene's rays finish out of order, so records of one level can be pushed while a few suspended rays of
     // the level above are still walking: the in-order bound does not hold and the capacity is a heuristic
     // (2x the bound, never seen exceeded); rt_render doubles spill_factor and renders again on RT_E_OVERFLOW.
-    a.max_spill = sc->use_bvh ? 2 * sc->spill_factor * levels : levels;
+    // (+1: the second pass of a small frame puts up to 32 list records on top of a pool that still holds up to 16)
+    a.max_spill = (sc->use_bvh ? 2 * sc->spill_factor * levels : levels) + 1;
 
     // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
     const float* M = cam->cam_to_world;
@@ -352,19 +372,59 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring)).pool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * ring : 0));
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
+    // Small frames (few pixel-samples, each a ray tree of up to thousands of rays: 640x480x1 has 307 200 trees of up to
+    // 3 928 rays, 55 on average, and a wave's fair share is ~50 iterations of 64 rays — less than one large tree) are
+    // rendered in two passes: primaries first, their hit records to a list, then the subtrees of those records shared
+    // out record by record among all the waves the chip holds.  (A pass is a launch: no wave ever waits for another.)
+    const unsigned long long total = c.total;
+    const size_t list_cap = 4 * (size_t)total;
+    const size_t list_bytes = (size_t)(nf + 3) * list_cap * sizeof(uint32_t);
+    bool two_pass = total <= kTwoPassMaxSamples && p->two_pass == 0;
+    unsigned char* list_base = nullptr;
+    if (two_pass) {
+        if (noalloc) {
+            if (list_bytes * 2 <= ws.avail) { list_base = ws.base; ws.base += (list_bytes + 255) & ~(size_t)255; ws.avail -= (list_bytes + 255) & ~(size_t)255; }
+            else two_pass = false;
+        } else {
+            rc = ensure_buffer(reinterpret_cast<void**>(&sc->d_list), &sc->list_bytes, list_bytes);
+            if (rc) return rc;
+            list_base = sc->d_list;
+        }
+    }
+    if (two_pass) {
+        c.list = reinterpret_cast<uint32_t*>(list_base);
+        c.list_cap = (unsigned int)list_cap;
+        {   // inverse of the hand-out multiplier modulo npix (extended Euclid): position of a pixel in the hand-out order
+            long long t0 = 0, t1 = 1, r0 = npix, r1 = c.scatter;
+            while (r1 != 0) { const long long qq = r0 / r1, t2 = t0 - qq * t1, r2 = r0 - qq * r1; t0 = t1; t1 = t2; r0 = r1; r1 = r2; }
+            c.scatter_inv = (unsigned int)((t0 % npix + npix) % npix);
+        }
+        // entries of children that never exist (misses, lights, surfaces with fewer than four samples) stay empty
+        HIP_TRY(hipMemsetAsync(c.list + 9 * list_cap, 0, list_cap * sizeof(uint32_t), stream));
+    }
+
+    auto launch = [&](auto phase_tag) -> int {
+        constexpr int PH = decltype(phase_tag)::value;
+        if (sc->use_bvh)
+            return ring == 8 ? (node64 ? launch_trace<true, true, 8, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                       : launch_trace<false, true, 8, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws))
+                             : (node64 ? launch_trace<true, true, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                       : launch_trace<false, true, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws));
+        return node64 ? launch_trace<true, false, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                      : launch_trace<false, false, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws);
+    };
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
-    HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long) * kCounterParts * kCounterStride, stream));
     HIP_TRY(hipMemsetAsync(accum, 0, accum_bytes, stream));
-    if (d_stats) HIP_TRY(hipMemsetAsync(d_stats, 0, RT_STATS_WORDS * sizeof(uint64_t), stream));
-    if (sc->use_bvh)
-        rc = ring == 8 ? (node64 ? launch_trace<true, true, 8>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                                 : launch_trace<false, true, 8>(sc, c, a, p->waves_per_cu, smem, stream, ws))
-                       : (node64 ? launch_trace<true, true, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                                 : launch_trace<false, true, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws));
-    else
-        rc = node64 ? launch_trace<true, false, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                    : launch_trace<false, false, 16>(sc, c, a, p->waves_per_cu, smem, stream, ws);
+    if (d_stats) HIP_TRY(hipMemsetAsync(sc->d_statpart, 0, sizeof(unsigned long long) * kStatsParts * kStatsWords, stream));
+    if (two_pass) {
+        rc = launch(std::integral_constant<int, 1>());
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long) * kCounterParts * kCounterStride, stream));
+        rc = launch(std::integral_constant<int, 2>());
+    } else rc = launch(std::integral_constant<int, 0>());
     if (rc) return rc;
+    if (d_stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(kStatsWords), dim3(64), 0, stream, sc->d_statpart, reinterpret_cast<unsigned long long*>(d_stats));
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, accum, d_rgba,
                        npix, p->spp);
     HIP_TRY(hipGetLastError());
@@ -559,7 +619,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_status), sizeof(int));
     if (e == hipSuccess) e = hipMemset(sc->d_status, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_counter), sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_counter), sizeof(unsigned long long) * kCounterParts * kCounterStride);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_statpart), sizeof(unsigned long long) * kStatsParts * kStatsWords);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&sc->num_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) {
         rt_scene_destroy(sc);
@@ -582,11 +643,13 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_shade) (void)hipFree(sc->d_shade);
     if (sc->d_status) (void)hipFree(sc->d_status);
     if (sc->d_counter) (void)hipFree(sc->d_counter);
+    if (sc->d_statpart) (void)hipFree(sc->d_statpart);
     if (sc->d_accum) (void)hipFree(sc->d_accum);
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_gstack) (void)hipFree(sc->d_gstack);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes);
     if (sc->d_pdata) (void)hipFree(sc->d_pdata);
+    if (sc->d_list) (void)hipFree(sc->d_list);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
     delete sc;

@@ -43,14 +43,25 @@ struct ColdArgs {
     int H, ncols;
     unsigned long long total;       // pixel-samples of this launch = ncols * H * spp
     unsigned int npix, scatter;     // hand-out order: pixel (i * scatter) mod npix, gcd(scatter, npix) = 1
-    unsigned long long* counter;    // next pixel-sample to hand out
+    unsigned long long* counter;    // hand-out counter(s).  One for the pixel-samples of a frame; kCounterParts for the list
+                                    // entries of the second pass of a small frame, part p dealing the p-th share of the
+                                    // list: tens of thousands of hand-outs within half a millisecond queue at a single
+                                    // address (~12 ns per same-address atomic; measured 1.00 -> 0.80 ms on 640x480x1,
+                                    // while large frames are 6 % FASTER with the single counter)
     unsigned long long* accum;      // [ncols*H*4] per-pixel radiance sums (r,g,b,pad), 32.32 fixed point
     float* depth;                   // [ncols*H]
     unsigned long long* ids;        // [ncols*H] or null
-    unsigned long long* stats;      // RT_STATS_WORDS u64, or null
+    unsigned long long* stats;      // [kStatsParts][RT_STATS_WORDS] partial sums (wave w adds to part w % kStatsParts;
+                                    // stats_reduce_kernel folds them into the caller's array), or null
     int* status;                    // overflow flag
     uint32_t* spill;                // [waves][max_spill][NF*64] pool blocks spilled to HBM
     uint32_t* gstack;               // [waves][kBvhStack][64] backing store of the traversal stacks (BVH)
+    // two-pass rendering of small frames (RenderArgs::phase): the records of the primary hits, field-major
+    uint32_t* list;                 // [NF + 3][list_cap]: the record fields, then RNG counter (lo, hi), compact pixel index;
+                                    // entry = (child of the primary) * total + position of the pixel-sample in the hand-out
+                                    // order: the four subtrees of one expensive sample lie far apart in the list
+    unsigned int list_cap;          // = 4 * total
+    unsigned int scatter_inv;       // inverse of `scatter` modulo npix
 };
 
 // Hot constants: live in SGPRs for the whole kernel.
@@ -61,6 +72,12 @@ struct RenderArgs {
     uint32_t seed_lo, seed_hi;
     int min_active;                 // BVH: leave the traversal when fewer lanes than this are still walking
     int leaf_min;                   // BVH: lanes that must wait at a leaf before the leaves are tested
+    int phase_unused;               // (PHASE is a template parameter of trace_kernel)  0: the whole tree of a pixel-sample in one launch.  Small frames (few pixel-samples,
+                                    // each a tree of up to thousands of rays, as much as a wave's whole share) take two:
+                                    // 1: the primary rays and their children; the hit records of the children go to a
+                                    // list in HBM instead of the pool; 2: the waves pull records from that list instead
+                                    // of starting pixel-samples, so a tree is shared by up to sixteen waves
+    int list_chunk, list_low;       // second pass: list entries taken at a time; taken when the pool holds at most list_low records
     int lamb;                       // SampleCount of Lambertian surfaces that do not override it (Surface.fs:63: 4)
     int estimator;                  // RT_ESTIMATOR_*: 0 = the reference's branching estimator, 1 = single path
 };
@@ -75,6 +92,14 @@ RT_DEV const ColdArgs* cold_args()
 // bits of the status word a launch leaves behind (rt_scene_status)
 constexpr int kStatusOverflow = 1;      // a wave's record pool overflowed
 constexpr int kStatusRange = 2;         // a radiance contribution was NaN, infinite or >= 2^31 and was dropped
+
+// Waves add their statistics to one of kStatsParts copies of the array: thousands of waves leaving a small frame at
+// the same moment otherwise queue at one cache line (measured on 640x480x1: 5632 waves x 10 atomics = 0.4 ms per launch).
+constexpr int kCounterParts = 16;       // each counter 128 bytes from the next (its own cache line)
+constexpr int kCounterStride = 16;      // in u64
+constexpr int kListChunk = 32;          // list entries a wave takes at a time in the second pass of a small frame
+constexpr int kStatsParts = 128;
+constexpr int kStatsWords = 20;         // == RT_STATS_WORDS (include/rt_abi.h)
 
 // meta word of a record
 //   bits 0..7 slot | 8..12 level | 13..15 children | 16..17 kind | 18..19 geometry type | 20..31 surface index
@@ -131,8 +156,8 @@ struct LdsLayout {
 //          14 waves on a CU instead of 12 (the traversal is latency-bound: measured +10 % on the 4K mixed scene)
 //          at the price of a few spilled registers and of more stack traffic to HBM, which is why scenes with
 //          deep, crowded trees (the 1M-sphere field: -11 %) use the 16-entry variant at 3 waves per SIMD.
-template <bool NODE64, bool BVH, int RING>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING == 8 ? 4 : 3) : 5))) void trace_kernel(const ColdArgs cold_unused, const RenderArgs a,
+template <bool NODE64, bool BVH, int RING, int PHASE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING == 8 ? 4 : 3) : 6))) void trace_kernel(const ColdArgs cold_unused, const RenderArgs a,
                                                    const GeomRec* __restrict__ geom,
                                                    const ShadeRec* __restrict__ shade, const BvhRef bvh)
 {
@@ -189,12 +214,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
     uint32_t n_lamb = 0, n_metal = 0, n_diel = 0;   // child rays intersected, by the kind that scattered them
     int spins = 0;
+    uint32_t n_refill = 0;                      // hand-outs this wave has taken (two-pass frames)
 #ifdef RT_PHASE_TIMING
     unsigned long long ph_gen = 0, ph_scan = 0, ph_trav = 0, ph_shade = 0, ph_t = __builtin_readcyclecounter();
 #define RT_PHASE(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - ph_t; ph_t = now_; }
 #else
 #define RT_PHASE(acc)
 #endif
+
+    // Hand-out: `want` consecutive items of [0, total) from the wave's current part of the index space; when that
+    // part is used up the wave moves to the next part that has items left.  Returns the number taken (0: none left).
+    constexpr int PARTS = (PHASE == 2) ? kCounterParts : 1;
+    int cur_part = (int)(blockIdx.x % PARTS);
+    auto take = [&](int want, unsigned long long total, unsigned long long& base_out) -> int {
+        const ColdArgs* ca = cold_args();
+        const unsigned long long per = (total + PARTS - 1) / PARTS;
+        while (true) {
+            const unsigned long long lo = (unsigned long long)cur_part * per;
+            const unsigned long long hi = (lo + per < total) ? lo + per : total;
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(ca->counter + cur_part * kCounterStride, (unsigned long long)want);
+            b = __shfl(b, 0) + lo;
+            if (b < hi) { base_out = b; return (b + (unsigned long long)want <= hi) ? want : (int)(hi - b); }
+            if (PARTS == 1) return 0;
+            // this part is used up: look at all the counters at once for a part with items left, nearest after this one
+            unsigned long long cv = ~0ull;
+            if (lane < PARTS) cv = __hip_atomic_load(ca->counter + lane * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long llo = (unsigned long long)lane * per;
+            const unsigned long long lhi = (llo + per < total) ? llo + per : total;
+            const uint32_t avail = (uint32_t)__ballot(lane < PARTS && llo < lhi && cv < lhi - llo);
+            if (avail == 0u) return 0;
+            const uint32_t rot = ((avail >> cur_part) | (avail << (PARTS - cur_part))) & ((1u << PARTS) - 1u);
+            cur_part = (cur_part + __builtin_ctz(rot)) % PARTS;
+        }
+    };
 
     // Per-lane ray state.  In BVH mode a lane may keep its ray over several iterations: when most lanes of the
     // wave have finished their traversal, the wave leaves the traversal loop, handles the finished rays,
@@ -221,6 +274,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             top = 64;
             __syncthreads();
         }
+        // ---- second pass of a small frame: when the pool runs low, hit records of the first pass are taken from the
+        // list in HBM and put on top of it (here, at the top of the loop, no lane still reads a popped record).  The
+        // list has four entries per pixel-sample, in hand-out order (scattered over the image, so neighbours in the
+        // list are not neighbours in cost), valid where a child of the primary hit a scattering surface.
+        if (PHASE == 2 && nspill == 0 && top <= a.list_low && !exhausted && __popcll(freemask) >= 8) {
+            const ColdArgs* ca = cold_args();
+            const int want = min(a.list_chunk, __popcll(freemask));
+            unsigned long long base = 0;
+            const int n = take(want, (unsigned long long)ca->list_cap, base);
+            if (n == 0) exhausted = true;
+            else {
+                const size_t cap = ca->list_cap;
+                const uint32_t* lr = ca->list + (size_t)base + lane;
+                const uint32_t lmeta = (lane < n) ? lr[(F_META / 64) * cap] : 0u;
+                const bool valid = ((lmeta >> 13) & 7u) != 0u;
+                const unsigned long long vm = __ballot(valid);
+                const int nv = __popcll(vm);
+                const bool offer = ((freemask >> lane) & 1ull) != 0 && mbcnt64(freemask) < nv;
+                if (offer) map[mbcnt64(freemask)] = (uint32_t)lane;
+                freemask &= ~__ballot(offer);
+                __syncthreads();
+                if (valid) {
+                    const int sl = (int)map[mbcnt64(vm)];
+                    uint32_t* wb = rec_base(top + mbcnt64(vm));
+#pragma unroll
+                    for (int f = 0; f < NF; f++) {
+                        uint32_t v = (f == F_META / 64) ? ((lmeta & ~0xffu) | (uint32_t)sl) : lr[f * cap];
+                        wb[f * 64] = v;
+                    }
+                    sl_ps[sl] = (unsigned long long)lr[NF * cap] | ((unsigned long long)lr[(NF + 1) * cap] << 32);
+                    sl_pix[sl] = lr[(NF + 2) * cap];
+                    sl_pend[sl] = 1u;
+                    sl_acc[sl * 3 + 0] = 0ull; sl_acc[sl * 3 + 1] = 0ull; sl_acc[sl * 3 + 2] = 0ull;
+                }
+                top += nv;
+                __syncthreads();
+            }
+        }
         // ---- take the top records whose children fit in 64 lanes (prefix sum over ballots)
         int nchild = 0;
         uint32_t mp = 0u;
@@ -245,7 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         }
         // ---- the pool is drained: start new pixel-samples in the free lanes
         int nprim = 0;
-        if (top == 0 && nspill == 0 && nchild < nfree && !exhausted) {
+        if (PHASE != 2 && top == 0 && nspill == 0 && nchild < nfree && !exhausted) {
             // pull exactly as many pixel-samples as there are free lanes (and free slots): one returning
             // atomic per refill keeps the hand-out fine-grained, so no wave is left holding a queue of
             // expensive pixels while the others have finished
@@ -253,16 +344,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             if (want > 0) {
                 const ColdArgs* ca = cold_args();
                 unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(ca->counter, (unsigned long long)want);
-                base = __shfl(base, 0);
-                const unsigned long long total = ca->total;
-                if (base >= total) exhausted = true;
-                else { res_next = base; nprim = (base + (unsigned long long)want <= total) ? want : (int)(total - base); }
+                unsigned long long limit = ca->total;
+                if (PHASE == 1) {
+                    // primaries cost about the same everywhere: every wave owns one contiguous range of the hand-out
+                    // order, no shared counter (all the waves of a small frame would hit it in the same instant)
+                    const unsigned long long per = (limit + gridDim.x - 1) / gridDim.x;
+                    base = (unsigned long long)blockIdx.x * per;
+                    limit = (base + per < limit) ? base + per : limit;
+                    base += (unsigned long long)n_refill;
+                } else {
+                    const int n = take(want, limit, base);
+                    limit = base + (unsigned long long)n;       // (n == 0: nothing left)
+                    if (n == 0) base = limit = 0;
+                }
+                if (base >= limit) exhausted = true;
+                else {
+                    res_next = base;
+                    nprim = (base + (unsigned long long)want <= limit) ? want : (int)(limit - base);
+                    n_refill += (uint32_t)nprim;
+                }
             }
         }
         if (nchild + nprim == 0 && busymask == 0ull) {
             if (nspill > 0) continue;           // (cannot happen: a reloaded block always yields children)
             if (exhausted) break;               // nothing in the pool, nothing left to start
+            if (PHASE == 2) continue;         // a hand-out without a valid entry (sky, lights): take the next one
             if (++spins > 4) { overflow = true; break; }   // cannot happen (all slots are free here): never spin
             continue;
         }
@@ -499,8 +605,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             }
         }
         // ---- compaction: hits on scattering surfaces become records, deepest on top
-        const unsigned long long pm = __ballot(push);
-        const int npush = __popcll(pm);
+        unsigned long long pm = __ballot(push);
+        int npush = __popcll(pm);
+        if (PHASE == 1 && __ballot(alive && !busy && clevel == 1) != 0ull) {
+            // ---- first pass of a small frame: every child of a primary that has finished its closest-hit query fills
+            // its entry of the list in HBM — the hit record if its subtree is to be traced, else stays without children
+            // (the meta plane of the list is cleared before the launch: entries of children that never existed)
+            if (alive && !busy && clevel == 1 && push) {
+                const ColdArgs* ca = cold_args();
+                const size_t cap = ca->list_cap;
+                const unsigned long long ps = sl_ps[slot];
+                const uint32_t o = sl_pix[slot];
+                const unsigned long long o64 = ((unsigned long long)o * (unsigned long long)ca->scatter_inv) % (unsigned long long)ca->npix;
+                const unsigned long long q = o64 * (unsigned long long)spp + ps % (unsigned long long)spp;
+                uint32_t* lw = ca->list + (size_t)((unsigned long long)(cnode - 1) * ca->total + q);
+                lw[(F_PX / 64) * cap] = __float_as_uint(P.x); lw[(F_PY / 64) * cap] = __float_as_uint(P.y); lw[(F_PZ / 64) * cap] = __float_as_uint(P.z);
+                lw[(F_DX / 64) * cap] = __float_as_uint(Dn.x); lw[(F_DY / 64) * cap] = __float_as_uint(Dn.y); lw[(F_DZ / 64) * cap] = __float_as_uint(Dn.z);
+                lw[(F_BX / 64) * cap] = __float_as_uint(beta.x); lw[(F_BY / 64) * cap] = __float_as_uint(beta.y); lw[(F_BZ / 64) * cap] = __float_as_uint(beta.z);
+                lw[(F_META / 64) * cap] = make_meta(0, clevel, hn, hinfo & 3, (hinfo >> 5) & 3, BVH ? 0 : hidx);
+                if (BVH) lw[(F_SURF / 64) * cap] = (uint32_t)hidx;
+                lw[(F_NODE / 64) * cap] = (uint32_t)cnode;
+                if (NODE64) lw[(F_NODEHI / 64) * cap] = (uint32_t)(cnode >> 32);
+                lw[NF * cap] = (uint32_t)ps; lw[(NF + 1) * cap] = (uint32_t)(ps >> 32); lw[(NF + 2) * cap] = o;
+            }
+            if (clevel == 1) push = false;
+            pm = __ballot(push);
+            npush = __popcll(pm);
+        }
         if (top + npush > a.nblk * 64) {
             // ---- no room: spill the bottom block of the ring (top >= 64 here, so it is full)
             if (nspill < a.max_spill) {
@@ -562,7 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
 
     // ================= statistics ================================================================
     const ColdArgs* ca = cold_args();
-    unsigned long long* stats = ca->stats;
+    unsigned long long* stats = ca->stats ? ca->stats + (size_t)(blockIdx.x % kStatsParts) * kStatsWords : nullptr;
     if (stats) {
         unsigned long long r = nrays, nn = n_nodes, np = n_prims;
         float m = maxd;
@@ -582,6 +713,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             atomicAdd(stats + 5, (unsigned long long)n_diel);
             atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
+            atomicMax(stats + 18, __builtin_readcyclecounter() - t_start);
             if (BVH) {
                 atomicAdd(stats + 8, nn); atomicAdd(stats + 9, np);
                 atomicAdd(stats + 10, (unsigned long long)n_rin); atomicAdd(stats + 11, (unsigned long long)n_rlf);
@@ -626,6 +758,25 @@ __global__ __launch_bounds__(256) void place_columns_kernel(const float* __restr
     *reinterpret_cast<float4*>(f_rgba + 4 * dst) = *reinterpret_cast<const float4*>(rgba + 4 * o);
     f_depth[dst] = depth[o];
     if (ids) f_ids[dst] = ids[o];
+}
+
+// Folds the kStatsParts partial statistics arrays into the caller's (words 1 and 18 are maxima, the others sums).
+// One 64-lane block per word.
+__global__ __launch_bounds__(64) void stats_reduce_kernel(const unsigned long long* __restrict__ parts, unsigned long long* __restrict__ out)
+{
+    const int w = blockIdx.x;
+    const bool is_max = (w == 1 || w == 18);
+    unsigned long long v = 0ull;
+    for (int p = threadIdx.x; p < kStatsParts; p += 64) {
+        const unsigned long long x = parts[(size_t)p * kStatsWords + w];
+        v = is_max ? (x > v ? x : v) : v + x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long x = __shfl_xor(v, off);
+        v = is_max ? (x > v ? x : v) : v + x;
+    }
+    if (threadIdx.x == 0) out[w] = v;
 }
 
 // findClosestIntersection as a batch query (Surface.fs:49-58): one ray per thread.

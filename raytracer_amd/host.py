@@ -366,7 +366,7 @@ def make_camera(origin=(-3.0, 6.0, 15.0), look_at=(-1.0, 1.0, -10.0), up=(0.0, 1
 
 def make_params(width=800, height=640, spp=1, max_trace_depth=5, background=(0.0, 0.0, 0.0), jitter=1,
                 seed=1, lambertian_samples=0, x_begin=0, x_end=None, x_step=1, waves_per_cu=0, pool_blocks=0,
-                estimator=0, bvh_ring=0, bvh_min_active=0):
+                estimator=0, bvh_ring=0, bvh_min_active=0, two_pass=0):
     """Scene.fs:18-20,31-32 defaults."""
     p = abi.rt_params()
     p.width, p.height, p.spp, p.max_trace_depth = width, height, spp, max_trace_depth
@@ -374,7 +374,7 @@ def make_params(width=800, height=640, spp=1, max_trace_depth=5, background=(0.0
     p.jitter, p.seed, p.lambertian_samples = jitter, seed, lambertian_samples
     p.x_begin, p.x_end, p.x_step = x_begin, width if x_end is None else x_end, x_step
     p.waves_per_cu, p.pool_blocks = waves_per_cu, pool_blocks
-    p.estimator, p.bvh_ring, p.bvh_min_active = estimator, bvh_ring, bvh_min_active
+    p.estimator, p.bvh_ring, p.bvh_min_active, p.two_pass = estimator, bvh_ring, bvh_min_active, two_pass
     return p
 
 

@@ -18,7 +18,7 @@ class Scene:
     def __init__(self, surfaces=None, width=800, height=640, samplesPerPixel=1, maxTraceDepth=5,
                  backgroundColor=(0.0, 0.0, 0.0), cameraOriginWS=(-3.0, 6.0, 15.0), lookAt=(-1.0, 1.0, -10.0),
                  fov=None, seed=1, jitter=1, lambertian_samples=0, device=0, waves_per_cu=0, pool_blocks=0,
-                 estimator=0, bvh_ring=0, bvh_min_active=0):
+                 estimator=0, bvh_ring=0, bvh_min_active=0, two_pass=0):
         if isinstance(surfaces, np.ndarray):
             self.surfaces = np.ascontiguousarray(surfaces)          # flat rt_surface records (raytracer_amd.scenes)
         else:
@@ -30,6 +30,7 @@ class Scene:
         self.seed, self.jitter, self.lambertian_samples = int(seed), int(jitter), int(lambertian_samples)
         self.device, self.waves_per_cu, self.pool_blocks = int(device), int(waves_per_cu), int(pool_blocks)
         self.estimator, self.bvh_ring, self.bvh_min_active = int(estimator), int(bvh_ring), int(bvh_min_active)
+        self.two_pass = int(two_pass)
         self.frameBuffer = np.zeros((self.width, self.height, 4), dtype=np.float32)                  # Scene.fs:28
         self.depthBuffer = np.full((self.width, self.height), np.finfo(np.float32).max, dtype=np.float32)  # Scene.fs:29
         self.objectIds = np.zeros((self.width, self.height), dtype=np.uint64)
@@ -43,7 +44,7 @@ class Scene:
         return host.make_params(self.width, self.height, self.samplesPerPixel, self.maxTraceDepth,
                                 self.backgroundColor, self.jitter, self.seed, self.lambertian_samples,
                                 x_begin, x_end, x_step, self.waves_per_cu, self.pool_blocks,
-                                self.estimator, self.bvh_ring, self.bvh_min_active)
+                                self.estimator, self.bvh_ring, self.bvh_min_active, self.two_pass)
 
     def upload(self):
         """Flatten the surfaces and upload them once to HBM (rt_scene_create)."""

@@ -24,7 +24,7 @@ def test_header_compiles_as_c_and_layouts_match_ctypes():
     src = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%d %%d %%zu %%zu %%u %%d\\n",' \
           'sizeof(rt_surface),sizeof(rt_camera),sizeof(rt_params),offsetof(rt_params,seed),offsetof(rt_params,x_begin),' \
           'offsetof(rt_surface,g),offsetof(rt_params,pool_blocks),RT_ABI_VERSION,RT_STATS_WORDS,' \
-          'offsetof(rt_params,estimator),offsetof(rt_params,reserved),RT_NOALLOC_SCRATCH_BYTES,RT_NOALLOC_MAX_PIXELS);return 0;}\n' % HEADER
+          'offsetof(rt_params,estimator),offsetof(rt_params,two_pass),RT_NOALLOC_SCRATCH_BYTES,RT_NOALLOC_MAX_PIXELS);return 0;}\n' % HEADER
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
@@ -32,8 +32,8 @@ def test_header_compiles_as_c_and_layouts_match_ctypes():
         out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
     got = [int(x) for x in out]
     want = [C.sizeof(abi.rt_surface), C.sizeof(abi.rt_camera), C.sizeof(abi.rt_params), abi.rt_params.seed.offset,
-            abi.rt_params.x_begin.offset, abi.rt_surface.g.offset, abi.rt_params.pool_blocks.offset, abi.RT_ABI_VERSION, 16,
-            abi.rt_params.estimator.offset, abi.rt_params.reserved.offset, abi.RT_NOALLOC_SCRATCH_BYTES, abi.RT_NOALLOC_MAX_PIXELS]
+            abi.rt_params.x_begin.offset, abi.rt_surface.g.offset, abi.rt_params.pool_blocks.offset, abi.RT_ABI_VERSION, 20,
+            abi.rt_params.estimator.offset, abi.rt_params.two_pass.offset, abi.RT_NOALLOC_SCRATCH_BYTES, abi.RT_NOALLOC_MAX_PIXELS]
     assert got == want
     assert (got[0], got[1], got[2]) == (104, 80, 80)
     assert abi.surface_dtype.itemsize == C.sizeof(abi.rt_surface)

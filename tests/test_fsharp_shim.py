@@ -58,7 +58,7 @@ def test_struct_layouts_match_the_header():
     _check("RtParams", abi.rt_params, {"max_trace_depth": ["maxTraceDepth"], "lambertian_samples": ["lambertianSamples"],
                                        "x_begin": ["xBegin"], "x_end": ["xEnd"], "x_step": ["xStep"],
                                        "waves_per_cu": ["wavesPerCu"], "pool_blocks": ["poolBlocks"],
-                                       "bvh_ring": ["bvhRing"], "bvh_min_active": ["bvhMinActive"]})
+                                       "bvh_ring": ["bvhRing"], "bvh_min_active": ["bvhMinActive"], "two_pass": ["twoPass"]})
     assert (C.sizeof(abi.rt_surface), C.sizeof(abi.rt_camera), C.sizeof(abi.rt_params)) == (104, 80, 80)
 
 

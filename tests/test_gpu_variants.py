@@ -103,3 +103,40 @@ def test_radiance_beyond_the_fixed_point_range_is_reported(value):
     # the handle stays usable
     good = Scene(width=48, height=36, samplesPerPixel=1, maxTraceDepth=2, jitter=0)
     _compare(good)
+
+
+# ---- small frames: two passes (primaries and their children, then the subtrees shared among all waves) ---------------
+@pytest.mark.parametrize("kw", [
+    dict(width=160, height=120, samplesPerPixel=1, maxTraceDepth=5, jitter=0),
+    dict(width=96, height=64, samplesPerPixel=5, maxTraceDepth=4, jitter=1, seed=3),
+    dict(width=64, height=48, samplesPerPixel=2, maxTraceDepth=0, jitter=1, seed=4),
+    dict(width=64, height=48, samplesPerPixel=2, maxTraceDepth=1, jitter=1, seed=4, backgroundColor=(0.3, 0.2, 0.1)),
+    dict(width=64, height=48, samplesPerPixel=3, maxTraceDepth=16, jitter=1, seed=5, lambertian_samples=1),
+    dict(width=64, height=48, samplesPerPixel=3, maxTraceDepth=8, jitter=1, seed=6, estimator=abi.ESTIMATOR_SINGLE_PATH),
+    dict(width=33, height=17, samplesPerPixel=2, maxTraceDepth=3, jitter=1, seed=7, lambertian_samples=3),
+])
+@pytest.mark.parametrize("mesh", [False, True])
+def test_two_pass_frames_equal_one_pass_frames_and_the_oracle(kw, mesh):
+    """Frames of at most 2^19 pixel-samples are rendered in two launches (rt_params.two_pass = 0); the image, the IDs,
+    the depth and the ray count must be those of the single launch (two_pass = 1) bit for bit, and the oracle's."""
+    surfaces = _mixed(10) if mesh else None
+    a = Scene(surfaces=surfaces, two_pass=0, **kw)
+    b = Scene(surfaces=surfaces, two_pass=1, **kw)
+    _compare(a)
+    b.renderScene()
+    assert np.array_equal(a.frameBuffer, b.frameBuffer) and np.array_equal(a.objectIds, b.objectIds)
+    assert np.array_equal(a.depthBuffer, b.depthBuffer) and a.rayCount == b.rayCount
+
+
+def test_two_pass_column_partition_and_empty_regions():
+    """Interleaved columns of a two-pass frame equal the full frame; a scene that is mostly sky (list chunks without a
+    single valid entry) terminates with the right image."""
+    s = Scene(width=200, height=150, samplesPerPixel=2, maxTraceDepth=5, jitter=1, seed=6)
+    s.renderScene()
+    for r in range(3):
+        rgba, depth, ids, _, _ = s.renderColumns(r, s.width, 3)
+        assert np.array_equal(rgba, s.frameBuffer[r::3]) and np.array_equal(ids, s.objectIds[r::3])
+    sky = Scene(surfaces=SD.spheres_simple + SD.lights_simple, width=320, height=240, samplesPerPixel=1, maxTraceDepth=4,
+                jitter=1, seed=2, cameraOriginWS=(0.0, 0.0, 60.0), lookAt=(0.0, 0.0, -1.0))
+    _compare(sky)
+    assert (sky.objectIds == 0).mean() > 0.9
