@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--pool-blocks", type=int, default=0)
+    ap.add_argument("--bvh-ring", type=int, default=0, help="tuning: 8 or 16 entries of the traversal stack in LDS (0 = by tree size)")
+    ap.add_argument("--bvh-min-active", type=int, default=0, help="tuning: refill threshold of the BVH kernels (0 = 28)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -157,7 +159,8 @@ def main():
         cfg = dict(WORKLOADS[wl])
         surfaces, extra_kw = workload_scene(wl)
         cfg.update(extra_kw)
-        sc = Scene(surfaces=surfaces, device=local_rank, waves_per_cu=args.waves_per_cu, pool_blocks=args.pool_blocks, **cfg)
+        sc = Scene(surfaces=surfaces, device=local_rank, waves_per_cu=args.waves_per_cu, pool_blocks=args.pool_blocks,
+                   bvh_ring=args.bvh_ring, bvh_min_active=args.bvh_min_active, **cfg)
         xb, xe, xs, ncols = multi.columns_of_rank(sc.width, rank, world)
         bufs = dict(
             rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),

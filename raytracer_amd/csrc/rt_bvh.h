@@ -23,8 +23,8 @@
 namespace rt {
 
 struct BvhRef {
-    const float4* __restrict__ nodes;     // 8 float4 per node
-    const float4* __restrict__ pdata;     // 3 float4 per primitive slot
+    const float4* __restrict__ nodes;     // 8 float4 per node, followed in the same allocation by the primitive records
+    uint32_t pdata_off;                   // byte offset of the records (3 float4 per primitive slot) from `nodes`
     int nnodes;
 };
 
@@ -136,7 +136,6 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     const uint32_t onx = (inv.x < 0.0f) ? 48u : 0u, ony = (inv.y < 0.0f) ? 64u : 16u, onz = (inv.z < 0.0f) ? 80u : 32u;
     const uint32_t ofx = 48u - onx, ofy = 80u - ony, ofz = 112u - onz;
     const char* const node_bytes = reinterpret_cast<const char*>(bvh.nodes);
-    const char* const pdata_bytes = reinterpret_cast<const char*>(bvh.pdata);
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kBvhDone;
         sp--;
@@ -151,33 +150,39 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         // a group steps when it is at least leaf_min lanes strong, the larger one in any case
         const bool do_in = in & ((n_in >= leaf_min) | (n_in >= n_lf));
         const bool do_leaf = lf & ((n_lf >= leaf_min) | (n_lf > n_in));
-        rounds_inner += __ballot(do_in) != 0ull ? 1u : 0u;      // wave-uniform statistics
-        rounds_leaf += __ballot(do_leaf) != 0ull ? 1u : 0u;
-        float4 nx4, ny4, nz4, fx4, fy4, fz4, rf;
-        float4 ra[kBvhLeafMax], rb[kBvhLeafMax], rc[kBvhLeafMax];
-        int cnt = 0;
-        if (do_in) {
-            const uint32_t nb = cur << 7;                    // 128 bytes per node; the array is < 4 GB (host check)
-            nx4 = *reinterpret_cast<const float4*>(node_bytes + (nb + onx)); fx4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ofx));
-            ny4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ony)); fy4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ofy));
-            nz4 = *reinterpret_cast<const float4*>(node_bytes + (nb + onz)); fz4 = *reinterpret_cast<const float4*>(node_bytes + (nb + ofz));
-            rf = *reinterpret_cast<const float4*>(node_bytes + (nb + 96u));
+        {   // wave-uniform statistics (kept out of the divergent steps: every lane's copy stays the same)
+            const int c_in = __popcll(__ballot(do_in)), c_lf = __popcll(__ballot(do_leaf));
+            rounds_inner += c_in != 0 ? 1u : 0u;
+            rounds_leaf += c_lf != 0 ? 1u : 0u;
+            nodes_visited += (uint32_t)c_in;
+            prims_tested += (uint32_t)(c_lf + __popcll(__ballot(do_leaf & ((cur & 7u) > 1u))));
         }
-        if (do_leaf) {
-            // 1..4 records of 3 float4, contiguous
-            const int first = (int)((cur & 0x7fffffffu) >> 3);
-            cnt = (int)(cur & 7u);
-#pragma unroll
-            for (int k = 0; k < kBvhLeafMax; k++) {
-                // 48-byte records addressed by 32-bit byte offsets from the uniform base (the array is < 4 GB)
-                const uint32_t off = (uint32_t)(first + ((k < cnt) ? k : cnt - 1)) * 48u;
-                const float4* p = reinterpret_cast<const float4*>(pdata_bytes + off);
-                ra[k] = p[0]; rb[k] = p[1]; rc[k] = p[2];
+        // Both groups load through the SAME seven 16-byte requests, each lane from its own addresses: a lane at an inner
+        // node the six plane vectors and the references of its node, a lane at a leaf its (up to) two records of three
+        // float4 — nodes and records share one allocation, so an address is a 32-bit offset from the uniform base.
+        // One set of 28 registers instead of two sets (28 + 24) in flight, seven VMEM instructions per round instead of
+        // thirteen when both groups step.
+        float4 d[7];
+        int cnt = 0;
+        if (do_in | do_leaf) {
+            uint32_t o0, o1;        // inner: the node; leaf: first and second record
+            if (do_in) { o0 = cur << 7; o1 = o0; }             // 128 bytes per node; the allocation is < 4 GB (host check)
+            else {
+                const uint32_t first = (cur & 0x7fffffffu) >> 3;
+                cnt = (int)(cur & 7u);
+                o0 = bvh.pdata_off + first * 48u;              // 48-byte records
+                o1 = o0 + ((cnt > 1) ? 48u : 0u);
             }
+            const uint32_t a0 = o0 + (do_in ? onx : 0u), a1 = o0 + (do_in ? ofx : 16u), a2 = o0 + (do_in ? ony : 32u);
+            const uint32_t a3 = o1 + (do_in ? ofy : 0u), a4 = o1 + (do_in ? onz : 16u), a5 = o1 + (do_in ? ofz : 32u), a6 = o1 + (do_in ? 96u : 32u);
+            d[0] = *reinterpret_cast<const float4*>(node_bytes + a0); d[1] = *reinterpret_cast<const float4*>(node_bytes + a1);
+            d[2] = *reinterpret_cast<const float4*>(node_bytes + a2); d[3] = *reinterpret_cast<const float4*>(node_bytes + a3);
+            d[4] = *reinterpret_cast<const float4*>(node_bytes + a4); d[5] = *reinterpret_cast<const float4*>(node_bytes + a5);
+            d[6] = *reinterpret_cast<const float4*>(node_bytes + a6);
         }
         if (do_in) {
             // ---- inner node: four slab tests
-            nodes_visited++;
+            const float4 nx4 = d[0], fx4 = d[1], ny4 = d[2], fy4 = d[3], nz4 = d[4], fz4 = d[5], rf = d[6];
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             float t0, t1, t2, t3;
             box_entry2(v2f{ nx4.x, nx4.y }, v2f{ ny4.x, ny4.y }, v2f{ nz4.x, nz4.y }, v2f{ fx4.x, fx4.y }, v2f{ fy4.x, fy4.y }, v2f{ fz4.x, fz4.y },
@@ -191,10 +196,21 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             // free slots (room for three is made first, so they never land on a live entry).
             const bool h2 = t2 < kFltMax, h3 = t3 < kFltMax;
             const int nh = (t1 < kFltMax ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
-            if (SPILL) while (sp + 3 - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
-            stack[(sp & (K - 1)) * stride] = h3 ? r3 : (h2 ? r2 : r1);
-            stack[((sp + 1) & (K - 1)) * stride] = h3 ? r2 : r1;
-            stack[((sp + 2) & (K - 1)) * stride] = r1;
+            if (SPILL && K <= 8) {
+                // (a 16-entry ring has room to spare and its kernel no LDS to spare: it keeps the simpler rule below)
+                // room for exactly the nh entries pushed; the stores beyond the new top go to a dump row behind the
+                // ring (row K), so that they cannot land on a live entry of a full ring.  (Making room for three
+                // whatever nh is cost the 8-entry ring three of its entries: 0.22 TB of spill writes per 4K frame.)
+                while (sp + nh - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
+                stack[((0 < nh) ? (sp & (K - 1)) : K) * stride] = h3 ? r3 : (h2 ? r2 : r1);
+                stack[((1 < nh) ? ((sp + 1) & (K - 1)) : K) * stride] = h3 ? r2 : r1;
+                stack[((2 < nh) ? ((sp + 2) & (K - 1)) : K) * stride] = r1;
+            } else {
+                if (SPILL) while (sp + 3 - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
+                stack[(sp & (K - 1)) * stride] = h3 ? r3 : (h2 ? r2 : r1);
+                stack[((sp + 1) & (K - 1)) * stride] = h3 ? r2 : r1;
+                stack[((sp + 2) & (K - 1)) * stride] = r1;
+            }
             sp += nh;
             cur = (t0 < kFltMax) ? r0 : pop();
         }
@@ -203,13 +219,12 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
 #pragma unroll
             for (int k = 0; k < kBvhLeafMax; k++) {
                 float t; bool ok;
-                prim_test(ra[k], rb[k], rc[k], O, D, t, ok);
-                const int si = (int)__float_as_uint(rc[k].y);
+                prim_test(d[3 * k], d[3 * k + 1], d[3 * k + 2], O, D, t, ok);
+                const int si = (int)__float_as_uint(d[3 * k + 2].y);
                 const bool bt = better_hit(ok & (k < cnt), t, si, tmin, idx);
                 tmin = bt ? t : tmin;
                 idx = bt ? si : idx;
             }
-            prims_tested += (uint32_t)cnt;
             cur = pop();
         }
     }

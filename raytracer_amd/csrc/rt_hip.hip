@@ -145,7 +145,8 @@ struct rt_scene {
     int64_t nloose = 0;                        // entries of d_geom (all surfaces, or only the planes of a BVH scene)
     bool use_bvh = false;
     int spill_factor = 1;                      // BVH scenes: multiple of the in-order pool bound the spill area holds
-    float4* d_nodes = nullptr; float4* d_pdata = nullptr;
+    float4* d_nodes = nullptr;                 // the BVH: nodes, then the primitive records (one allocation, 32-bit offsets)
+    uint32_t pdata_off = 0;                    // byte offset of the records
     int nnodes = 0, bvh_depth = 0;
     int64_t nprims = 0;                        // primitives in the BVH
     int occ_smem[12] = { -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1 };   // LDS size the cached occupancy below was queried for (per kernel variant)
@@ -190,7 +191,7 @@ int check_params(const rt_camera* cam, const rt_params* p)
 BvhRef bvh_ref(const rt_scene* sc)
 {
     BvhRef b;
-    b.nodes = sc->d_nodes; b.pdata = sc->d_pdata; b.nnodes = sc->nnodes;
+    b.nodes = sc->d_nodes; b.pdata_off = sc->pdata_off; b.nnodes = sc->nnodes;
     return b;
 }
 
@@ -274,8 +275,6 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
 // A scene goes through the BVH when it has triangles or more spheres than a wave-uniform scan should test.
 constexpr int64_t kBvhThreshold = 64;
 constexpr int64_t kLooseSpheres = 16;
-// Up to this many primitives the 8-entry stack ring is used (measured: 100k triangles +2..10 %, 1M spheres -11 %).
-constexpr int64_t kBvhSmallTree = 262144;
 // Frames of at most this many pixel-samples are rendered in two passes (render_on_stream); the list of primary hit
 // records takes up to 4 x 64 bytes per pixel-sample.
 constexpr unsigned long long kTwoPassMaxSamples = 1ull << 19;
@@ -368,8 +367,10 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     const bool node64 = p->max_trace_depth > 13;
     const int nf = 11 + (node64 ? 1 : 0) + (sc->use_bvh ? 1 : 0);
     // LDS entries of the traversal stacks: see trace_kernel's RING
-    const int ring = p->bvh_ring ? p->bvh_ring : (sc->nprims <= kBvhSmallTree) ? 8 : 16;
-    const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring)).pool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * ring : 0));
+    // 8 entries for every tree since the ring makes room for exactly the entries pushed (rt_bvh.h): the 1M-sphere tree,
+    // which used to overflow the short ring into HBM (-11 %), now gains 10 % from the 15 instead of 12 waves per CU
+    const int ring = p->bvh_ring ? p->bvh_ring : 8;
+    const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring)).pool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * (ring + (ring <= 8 ? 1 : 0)) : 0));   // (+1: the dump row of the 8-entry traversal stacks)
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     // Small frames (few pixel-samples, each a ray tree of up to thousands of rays: 640x480x1 has 307 200 trees of up to
@@ -598,7 +599,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
         bvh_build(bprims, src_pdata, hb);
         if (3 * hb.depth + 1 > kBvhStack) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
         // the traversal addresses nodes and records by 32-bit byte offsets and leaf references hold 28-bit record indices
-        if (hb.nodes.size() * sizeof(float4) >= (1ull << 32) || hb.pdata.size() * sizeof(float4) >= (1ull << 32) || bprims.size() >= (1ull << 28)) {
+        if ((hb.nodes.size() + hb.pdata.size()) * sizeof(float4) >= (1ull << 32) || bprims.size() >= (1ull << 28)) {
             delete sc; return fail(RT_E_UNSUPPORTED, "BVH of %zu primitives is too large", bprims.size());
         }
         sc->nnodes = (int)(hb.nodes.size() / 8); sc->bvh_depth = hb.depth; sc->nprims = (int64_t)bprims.size();
@@ -612,10 +613,11 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_shade), sizeof(ShadeRec) * (n > 0 ? (size_t)n : 1));
     if (e == hipSuccess && n > 0) e = hipMemcpy(sc->d_shade, h_shade.data(), sizeof(ShadeRec) * (size_t)n, hipMemcpyHostToDevice);
     if (use_bvh && !hb.nodes.empty()) {
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), sizeof(float4) * hb.nodes.size());
-        if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), sizeof(float4) * hb.nodes.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_pdata), sizeof(float4) * hb.pdata.size());
-        if (e == hipSuccess) e = hipMemcpy(sc->d_pdata, hb.pdata.data(), sizeof(float4) * hb.pdata.size(), hipMemcpyHostToDevice);
+        const size_t nbytes = sizeof(float4) * hb.nodes.size(), pbytes = sizeof(float4) * hb.pdata.size();
+        sc->pdata_off = (uint32_t)nbytes;
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), nbytes + pbytes);
+        if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), nbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(sc->d_nodes) + nbytes, hb.pdata.data(), pbytes, hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_status), sizeof(int));
     if (e == hipSuccess) e = hipMemset(sc->d_status, 0, sizeof(int));
@@ -648,7 +650,6 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_gstack) (void)hipFree(sc->d_gstack);
     if (sc->d_nodes) (void)hipFree(sc->d_nodes);
-    if (sc->d_pdata) (void)hipFree(sc->d_pdata);
     if (sc->d_list) (void)hipFree(sc->d_list);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
     if (sc->d_frame) (void)hipFree(sc->d_frame);

@@ -206,8 +206,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     unsigned long long freemask = ~0ull >> (64 - SLOTS);   // free slots (wave-uniform)
     unsigned long long res_next = 0;            // first pixel-sample of the current refill
     bool exhausted = false;                     // the global counter has run past the end
-    uint32_t nrays = 0;                         // closest-hit queries by this lane
-    uint32_t n_nodes = 0, n_prims = 0;          // BVH nodes visited / primitives tested by this lane
+    uint32_t nrays = 0;                         // closest-hit queries by this wave
+    uint32_t n_nodes = 0, n_prims = 0;          // BVH nodes visited / primitives tested by this wave
     uint32_t n_rin = 0, n_rlf = 0;              // BVH traversal rounds with an inner / a leaf step (wave-uniform)
     float maxd = 0.0f;
     bool overflow = false;
@@ -218,8 +218,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
 #ifdef RT_PHASE_TIMING
     unsigned long long ph_gen = 0, ph_scan = 0, ph_trav = 0, ph_shade = 0, ph_t = __builtin_readcyclecounter();
 #define RT_PHASE(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - ph_t; ph_t = now_; }
+#ifdef RT_PHASE_FINE
+    unsigned long long ph_fine[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define RT_FINE(i) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_fine[i] += now_ - ph_t; ph_gen += now_ - ph_t; ph_t = now_; }
+#else
+#define RT_FINE(i)
+#endif
 #else
 #define RT_PHASE(acc)
+#define RT_FINE(i)
 #endif
 
     // Hand-out: `want` consecutive items of [0, total) from the wave's current part of the index space; when that
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     f3 O = F3(0, 0, 0), Dn = F3(0, 0, 0), beta = F3(1.0f, 1.0f, 1.0f);
     int slot = 0, clevel = 0; uint64_t cnode = 0;
     bool alive = false, owner = false, is_prim = false;
-    float dot_view = 1.0f; uint32_t prim_o = 0; bool prim_first = false;
+    bool prim_first = false;
     float tcur = 0.0f; int hidx = -1;
     uint32_t trav_cur = kBvhDone; int trav_sp = 0, trav_lo = 0;
     bool busy = false;                          // BVH: this lane's traversal is suspended, not finished
@@ -274,6 +281,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             top = 64;
             __syncthreads();
         }
+        RT_FINE(0)   // spill reload
         // ---- second pass of a small frame: when the pool runs low, hit records of the first pass are taken from the
         // list in HBM and put on top of it (here, at the top of the loop, no lane still reads a popped record).  The
         // list has four entries per pixel-sample, in hand-out order (scattered over the image, so neighbours in the
@@ -334,6 +342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             top -= __popcll(tk);
             __syncthreads();                    // map is reused for the slot allocation below
         }
+        RT_FINE(1)   // list install + pop
         // ---- the pool is drained: start new pixel-samples in the free lanes
         int nprim = 0;
         if (PHASE != 2 && top == 0 && nspill == 0 && nchild < nfree && !exhausted) {
@@ -373,6 +382,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             continue;
         }
         n_iter++; spins = 0;
+        RT_FINE(2)   // refill atomic
         const bool is_child = !busy && frank < nchild;
         const bool fresh_prim = !busy && !is_child && frank < nchild + nprim;
         int ckind = 0;                          // kind of the surface this lane's child ray leaves (0 = primary)
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             alive = false;                      // this lane intersects a ray
             owner = false;                      // this lane retires one pending unit of its slot
             is_prim = fresh_prim;
-            dot_view = 1.0f; prim_o = 0; prim_first = false;
+            prim_first = false;
         }
 
         if (nprim > 0) {
@@ -423,12 +433,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                              (dirCS.x * ca->rot[2] + dirCS.y * ca->rot[5]) + dirCS.z * ca->rot[8]);
                 Dn = make_ray_dir(normalize(dirT));
                 O = F3(ca->origin[0], ca->origin[1], ca->origin[2]);
-                dot_view = dot(F3(ca->look_n[0], ca->look_n[1], ca->look_n[2]), Dn);   // Scene.fs:76
                 alive = true; owner = true;
-                prim_o = o; prim_first = (s == 0);
+                prim_first = (s == 0);
             }
         }
 
+        RT_FINE(3)   // primary generation
         if (is_child) {
             // ============ rayTrace: one child of a popped record (Scene.fs:62-70) ============
             const int rec = top0 - 1 - (int)(mp >> 2);
@@ -459,6 +469,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             const float4 al = *reinterpret_cast<const float4*>(&sr->albedo[0]);
             const float4 nc = *reinterpret_cast<const float4*>(&sr->nc[0]);
             const f3 albedo = F3(al.x, al.y, al.z);
+#ifdef RT_PHASE_FINE
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            RT_FINE(4)   // record read + ShadeRec gather
+#endif
 
             // The three Scatter/Fresnel routines are interleaved so that their common steps (one
             // Vector3.Normalize each) run once for all lanes with per-lane operands: every lane still
@@ -555,8 +569,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         if (alive && !busy) {
             closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
             trav_cur = (BVH && bvh.nnodes) ? 0u : kBvhDone; trav_sp = 0; trav_lo = 0;   // BVH: start at the root (an empty tree has none)
-            nrays++;
         }
+        nrays += (uint32_t)__popcll(__ballot(alive && !busy));
         RT_PHASE(ph_scan)
         if (BVH) {
             // new and suspended rays walk the tree together; leave early only when other work can fill the lanes
@@ -581,10 +595,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 // Scene.fs:79: the primary's closest candidate is re-tested with dotView; planes then
                 // cull at TMax/dotView (Plane.fs:46).  A failed re-test is a miss, not the next hit.
                 const uint32_t hg = (hinfo >> 5) & 3;
-                if (is_prim && (hg == kGeomPlaneInf || hg == kGeomPlaneRect)) hit = t <= (kTMax / dot_view);
+                if (is_prim && (hg == kGeomPlaneInf || hg == kGeomPlaneRect)) {
+                    const ColdArgs* ca = cold_args();
+                    const float dot_view = dot(F3(ca->look_n[0], ca->look_n[1], ca->look_n[2]), Dn);   // Scene.fs:76
+                    hit = t <= (kTMax / dot_view);
+                }
             }
             if (is_prim && prim_first) {                               // Scene.fs:80 / :29
                 const ColdArgs* ca = cold_args();
+                const uint32_t prim_o = sl_pix[slot];
                 ca->depth[prim_o] = hit ? t : kFltMax;
                 if (ca->ids) ca->ids[prim_o] = hit ? shade[hidx].id : 0ull;
                 if (hit) maxd = fmaxf(maxd, t);
@@ -695,15 +714,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     const ColdArgs* ca = cold_args();
     unsigned long long* stats = ca->stats ? ca->stats + (size_t)(blockIdx.x % kStatsParts) * kStatsWords : nullptr;
     if (stats) {
-        unsigned long long r = nrays, nn = n_nodes, np = n_prims;
+        const unsigned long long r = nrays, nn = n_nodes, np = n_prims;      // wave-uniform counts
         float m = maxd;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            r += __shfl_xor(r, off);
-            nn += __shfl_xor(nn, off);
-            np += __shfl_xor(np, off);
-            m = fmaxf(m, __shfl_xor(m, off));
-        }
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if (lane == 0) {
             atomicAdd(stats + 0, r);
             atomicMax(reinterpret_cast<unsigned int*>(stats + 1), __float_as_uint(m));
@@ -719,6 +733,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 atomicAdd(stats + 10, (unsigned long long)n_rin); atomicAdd(stats + 11, (unsigned long long)n_rlf);
 #ifdef RT_PHASE_TIMING
                 atomicAdd(stats + 12, ph_gen); atomicAdd(stats + 13, ph_scan); atomicAdd(stats + 14, ph_trav); atomicAdd(stats + 15, ph_shade);
+#endif
+#ifdef RT_PHASE_FINE
+                atomicAdd(stats + 16, ph_fine[0]); atomicAdd(stats + 17, ph_fine[1]); atomicAdd(stats + 19, ph_fine[2]);
+                atomicAdd(stats + 8, ph_fine[3]); atomicAdd(stats + 9, ph_fine[4]);    // (debug build: on top of the node / primitive counts)
 #endif
             }
         }

@@ -1,0 +1,32 @@
+"""Properties of the compiled kernels that results depend on.  A render-kernel variant that spilled vector registers to
+scratch once corrupted its (wave-uniform) ray-kind counters: values kept in VGPRs and spilled inside divergent code came
+back stale for lanes that were inactive at the spill (rays by kind off by 30 %, nondeterministic; the image was not
+affected).  Every variant must therefore fit its register budget without scratch."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_kernel_spills_vector_registers_to_scratch():
+    csrc = os.path.join(ROOT, "raytracer_amd", "csrc")
+    out = subprocess.run(["make", "-C", csrc, "asm"], capture_output=True, text=True, check=True)
+    text = out.stdout + out.stderr
+    kernels = {}
+    cur = None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs Spill|ScratchSize \[bytes/lane\]|VGPRs|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and cur:
+            kernels[cur][m.group(1)] = int(m.group(2))
+    trace = {k: v for k, v in kernels.items() if "trace_kernel" in k}
+    assert len(trace) == 18, sorted(kernels)          # {NODE64} x {linear, BVH ring 8, BVH ring 16} x {pass 0, 1, 2}
+    for name, r in trace.items():
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name, r)
+        bvh = "Lb1ELi" in name.split("trace_kernelILb")[1][1:]
+        assert r["Occupancy [waves/SIMD]"] >= (4 if bvh else 6), (name, r)

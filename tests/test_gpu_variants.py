@@ -32,15 +32,16 @@ def test_bvh_ring_variants_match_oracle(ring, depth, lamb):
 
 
 @pytest.mark.parametrize("depth,lamb", [(3, 0), (16, 1)])
-def test_large_tree_selects_the_ring16_kernel_and_matches_the_bruteforce_oracle(depth, lamb):
-    """More than 262144 primitives: the library picks the 16-entry ring / 64-slot kernel by itself (the c5 bench path).
-    Tiny frame, the oracle scans all 270 000 spheres per ray."""
+@pytest.mark.parametrize("ring", [0, 16])
+def test_large_tree_matches_the_bruteforce_oracle(depth, lamb, ring):
+    """A tree of 270 000 spheres (the shape of the c5 bench scene) through the default kernel (8-entry stack ring) and
+    the 16-entry-ring / 64-slot variant.  Tiny frame, the oracle scans all 270 000 spheres per ray."""
     s = scenes.many_spheres(270_000, seed=5, environment=False)
     s["g"][:, :3] *= np.float32(0.25)           # [-125,125] x [0,12.5] x [-250,0]
     m = np.concatenate([s, scenes.reference_environment(1)])
     w, h = (32, 24) if depth < 8 else (16, 12)      # (dielectric splits double per bounce: ~100 rays per pixel at depth 16)
     _compare(Scene(surfaces=m, width=w, height=h, samplesPerPixel=1, maxTraceDepth=depth, jitter=1, seed=3,
-                   lambertian_samples=lamb, cameraOriginWS=(0.0, 20.0, 15.0), lookAt=(0.0, 2.0, -100.0)))
+                   lambertian_samples=lamb, cameraOriginWS=(0.0, 20.0, 15.0), lookAt=(0.0, 2.0, -100.0), bvh_ring=ring))
 
 
 @pytest.mark.parametrize("ring,min_active", [(8, 64), (8, 33), (16, 64), (8, 1)])

@@ -35,8 +35,8 @@ def _render(torch, scene, noalloc, cols=(0, None, 1)):
 
 def _same(a, b):
     assert np.array_equal(a["rgba"], b["rgba"]) and np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["ids"], b["ids"])
-    # ray count, max depth, Lambertian child rays (the loop-iteration, clock and wave counts depend on the number of waves)
-    for w in (0, 1, 3):
+    # ray count, max depth, child rays by kind (the loop-iteration, clock and wave counts depend on the number of waves)
+    for w in (0, 1, 3, 4, 5):
         assert a["stats"][w] == b["stats"][w], w
     assert a["stats"][0] > 0
 
