@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r01}; WL=${2:-c2}; EXTRA=${3:-}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
-CMD="python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-extra --no-cpu-baseline $EXTRA"
+CMD="python3 ${BENCH:-$R/bench.py} --workload $WL --steps 3 --warmup 1 --no-extra --no-cpu-baseline $EXTRA"
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc1 -o p -- $CMD > $OUT/pmc1.log 2>&1 || exit 2
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- $CMD > $OUT/pmc2.log 2>&1 || exit 3

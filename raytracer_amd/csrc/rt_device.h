@@ -233,12 +233,12 @@ RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D,
             const float b = dot(ctr, D);
             const float C = dot(ctr, ctr) - r[3];
             const float d = b * b - C;
-            const bool has = !(d < 0.0f) & !(fabsf(d * 1e3f) <= 0.125f);
+            const bool has = d * 1e3f > 0.125f;          // == !(d < 0) & !(|1000 d| <= 0.125) for every d that can still give a hit
             const float sq = sqrt_rn(d);
             const float i1 = -b + sq, i2 = -b - sq;
-            const float tboth = (i1 < i2) ? i1 : i2;
-            const float tone = (i1 < 0.0f) ? i2 : i1;
-            t = ((i1 >= kTMin) & (i2 >= kTMin)) ? tboth : tone;
+            // sq >= 0, so i1 >= i2: 'both >= TMin' is 'i2 >= TMin' and the smaller root is i2; otherwise the reference takes i1
+            // unless i1 < 0, and then either choice is below TMin and rejected (Sphere.fs:28-36 in 2 instead of 6 selects)
+            t = (i2 >= kTMin) ? i2 : i1;
             ok = has & (t > kTMin);
         } else {
             // Plane.fs:36-40,45-49

@@ -149,8 +149,8 @@ struct rt_scene {
     uint32_t pdata_off = 0;                    // byte offset of the records
     int nnodes = 0, bvh_depth = 0;
     int64_t nprims = 0;                        // primitives in the BVH
-    int occ_smem[12] = { -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1 };   // LDS size the cached occupancy below was queried for (per kernel variant)
-    int occ_per_cu[12] = { 0 };
+    int occ_smem[24] = { 0 };         // (0 = not queried yet) LDS size the cached occupancy below was queried for (per kernel variant)
+    int occ_per_cu[24] = { 0 };
     unsigned char* d_list = nullptr;    // small frames: hit records of the primary pass (grown on demand)
     size_t list_bytes = 0;
     float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
@@ -210,15 +210,16 @@ constexpr int kMinActiveDefault = 28;
 static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slots_of(true, 16), "refill threshold above the sample slots");
 
 // PHASE: 0 = one launch per frame; 1, 2 = the two passes of a small frame (trace_kernel)
-template <bool NODE64, bool BVH, int RING, int PHASE>
+// SINGLE: the single-path estimator (rt_params.estimator)
+template <bool NODE64, bool BVH, int RING, int PHASE, bool SINGLE>
 int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_cu,
                  size_t smem, hipStream_t stream, const Workspace& ws)
 {
     constexpr int phase = PHASE;
-    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING, PHASE>);
+    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING, PHASE, SINGLE>);
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     // the attribute and the occupancy query cost host time: once per (kernel, LDS size) and scene
-    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE;
+    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE + (SINGLE ? 12 : 0);
     int& cached_smem = sc->occ_smem[variant];
     int& cached_per_cu = sc->occ_per_cu[variant];
     if (cached_smem != (int)smem) {
@@ -266,7 +267,7 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
             c.gstack = sc->d_gstack;
         }
     }
-    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING, PHASE>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
+    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING, PHASE, SINGLE>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
                        bvh_ref(sc));
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -333,7 +334,6 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     a.lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
-    a.estimator = p->estimator;
     // second pass of a small frame: 32 list entries at a time, taken when the pool holds at most 16 records (measured on
     // 640x480x1: chunks of 8 / 16 entries 2.0 / 1.2 ms, thresholds 0 / 48 records 0.83 / 1.09 ms against 0.83 ms)
     a.list_chunk = kListChunk; a.list_low = 16;
@@ -404,15 +404,19 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
         HIP_TRY(hipMemsetAsync(c.list + 9 * list_cap, 0, list_cap * sizeof(uint32_t), stream));
     }
 
-    auto launch = [&](auto phase_tag) -> int {
+    auto launch_est = [&](auto phase_tag, auto est_tag) -> int {
         constexpr int PH = decltype(phase_tag)::value;
+        constexpr bool SP = decltype(est_tag)::value;
         if (sc->use_bvh)
-            return ring == 8 ? (node64 ? launch_trace<true, true, 8, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                                       : launch_trace<false, true, 8, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws))
-                             : (node64 ? launch_trace<true, true, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                                       : launch_trace<false, true, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws));
-        return node64 ? launch_trace<true, false, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                      : launch_trace<false, false, 16, PH>(sc, c, a, p->waves_per_cu, smem, stream, ws);
+            return ring == 8 ? (node64 ? launch_trace<true, true, 8, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                       : launch_trace<false, true, 8, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws))
+                             : (node64 ? launch_trace<true, true, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                       : launch_trace<false, true, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws));
+        return node64 ? launch_trace<true, false, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                      : launch_trace<false, false, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws);
+    };
+    auto launch = [&](auto phase_tag) -> int {
+        return p->estimator == RT_ESTIMATOR_SINGLE_PATH ? launch_est(phase_tag, std::true_type()) : launch_est(phase_tag, std::false_type());
     };
     HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long) * kCounterParts * kCounterStride, stream));

@@ -79,7 +79,7 @@ struct RenderArgs {
                                     // of starting pixel-samples, so a tree is shared by up to sixteen waves
     int list_chunk, list_low;       // second pass: list entries taken at a time; taken when the pool holds at most list_low records
     int lamb;                       // SampleCount of Lambertian surfaces that do not override it (Surface.fs:63: 4)
-    int estimator;                  // RT_ESTIMATOR_*: 0 = the reference's branching estimator, 1 = single path
+    int unused_;
 };
 
 RT_DEV const ColdArgs* cold_args()
@@ -116,15 +116,14 @@ RT_DEV int mbcnt64(unsigned long long m)
 }
 
 // radiance contribution -> signed 32.32 fixed point (two's complement in a u64).  Defined for finite |x| < 2^31
-// (the callers check that and flag anything else, see add_radiance); contributions below 2^-32 truncate toward
-// minus infinity, like every other bit below the quantum.
+// (the callers check that and flag anything else, see add_radiance): floor(x) in the high word, the fraction
+// x - floor(x), scaled by 2^32 and truncated, in the low word.  The fraction is exact in [0,1) except for a tiny
+// negative x (x = -1e-10: -1e-10 - (-1) rounds to 1.0f), where it is held at the largest float below 1: the value
+// converted is then off by less than 2^-24, always the same for the same x, so sums stay order-independent.
 RT_DEV unsigned long long to_fixed(float x)
 {
-    float fl = floorf(x);
-    float fr = x - fl;                                          // in [0,1]: exactly 1.0 only when a tiny negative x
-    const bool carry = fr >= 1.0f;                              // rounds up in the subtraction (x = -1e-10: -1 + 1.0)
-    fl = carry ? fl + 1.0f : fl;
-    fr = carry ? 0.0f : fr;
+    const float fl = floorf(x);
+    const float fr = fminf(x - fl, 0x1.fffffep-1f);
     const uint32_t lo = (uint32_t)(fr * 4294967296.0f);         // exact scaling, truncating convert, < 2^32
     const int32_t hi = (int32_t)fl;
     return ((unsigned long long)(uint32_t)hi << 32) | lo;
@@ -156,7 +155,7 @@ struct LdsLayout {
 //          14 waves on a CU instead of 12 (the traversal is latency-bound: measured +10 % on the 4K mixed scene)
 //          at the price of a few spilled registers and of more stack traffic to HBM, which is why scenes with
 //          deep, crowded trees (the 1M-sphere field: -11 %) use the 16-entry variant at 3 waves per SIMD.
-template <bool NODE64, bool BVH, int RING, int PHASE>
+template <bool NODE64, bool BVH, int RING, int PHASE, bool SINGLE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING == 8 ? 4 : 3) : 6))) void trace_kernel(const ColdArgs cold_unused, const RenderArgs a,
                                                    const GeomRec* __restrict__ geom,
                                                    const ShadeRec* __restrict__ shade, const BvhRef bvh)
@@ -186,14 +185,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         b = (b >= a.nblk) ? b - a.nblk : b;
         return pool + (b * (NF * 64) + (r & 63));
     };
-    bool range_err = false;                     // a radiance contribution was NaN, infinite or >= 2^31
-    // beta*E into the pixel-sample's fixed-point sum; a contribution the format cannot hold is dropped and flagged
+    // beta*E into the pixel-sample's fixed-point sum; a contribution the format cannot hold (NaN, infinite or
+    // >= 2^31) is dropped and flagged in the status word at once (it never happens with the reference's materials)
     auto add_radiance = [&](int sl, f3 v) {
         if (fixed_ok(v)) {
             atomicAdd(&sl_acc[sl * 3 + 0], to_fixed(v.x));
             atomicAdd(&sl_acc[sl * 3 + 1], to_fixed(v.y));
             atomicAdd(&sl_acc[sl * 3 + 2], to_fixed(v.z));
-        } else range_err = true;
+        } else atomicOr(cold_args()->status, kStatusRange);
     };
     enum { F_PX = 0, F_PY = 64, F_PZ = 128, F_DX = 192, F_DY = 256, F_DZ = 320, F_BX = 384, F_BY = 448, F_BZ = 512,
            F_META = 576, F_NODE = 640, F_NODEHI = 704, F_SURF = NODE64 ? 768 : 704 };
@@ -491,7 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             // estimator, the RandomFloat of Dielectric.Scatter (Surface.fs:157); the branching Dielectric draws nothing
             f3 rn = F3(0.0f, 1.0f, 0.0f);
             float rand_float = 0.0f;
-            if ((kind != kKindDielectric) | (a.estimator != 0)) rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode, rand_float);
+            if ((kind != kKindDielectric) | SINGLE) rn = hemisphere_sample(a.seed_lo, a.seed_hi, ps, cnode, rand_float);
             if (kind != kKindDielectric) {
                 // Lambertian.Scatter (Surface.fs:66-83) / Metal.Scatter (Surface.fs:93-109): hemisphere
                 // sample in the frame around the normal
@@ -522,7 +521,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 }
                 single = rounds_to(F, 1e3f, 1e3f);                  // Round(F,3) = 1: reflection only
                 w = (Din + fn * cos_i) * eta - fn * sqrt_rn(disc);  // refraction direction before Normalize
-                if (a.estimator) refr_pick = !(rand_float <= F);    // Surface.fs:158: reflect when RandomFloat <= reflectProb (F = 1 under TIR)
+                if (SINGLE) refr_pick = !(rand_float <= F);    // Surface.fs:158: reflect when RandomFloat <= reflectProb (F = 1 under TIR)
                 else if (child == 1) alive = !single;
             }
             const f3 u = normalize(w);
@@ -542,7 +541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 shd = albedo * (1.0f / 1.0f);
             } else {
                 // branching: (2*albedo*F)/2 == albedo*F exactly; single path: BRDF*(cos/PDF) = albedo*(1/1) (Surface.fs:28,162)
-                shd = albedo * (a.estimator ? (1.0f / 1.0f) : (child == 0) ? F : (1.0f - F));
+                shd = albedo * (SINGLE ? (1.0f / 1.0f) : (child == 0) ? F : (1.0f - F));
             }
             if (kind != kKindDielectric)
                 inv_n = (n == 1) ? 1.0f : (n == 2) ? 0.5f : (n == 3) ? (1.0f / 3.0f) : 0.25f;   // 1/n, correctly rounded
@@ -556,9 +555,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             }
         }
 
-        n_lamb += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindLambert));
-        n_metal += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindMetal));
-        n_diel += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindDielectric));
+        // rays by kind: per-lane counters in the linear-scan kernel (three registers it has to spare; measured 1.3 %
+        // faster than wave-uniform ones, which cost scalar registers the closest-hit loop wants), wave-uniform in the
+        // BVH kernels (which have no vector register to spare)
+        if (BVH) {
+            n_lamb += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindLambert));
+            n_metal += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindMetal));
+            n_diel += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindDielectric));
+        } else {
+            n_lamb += (alive && ckind == kKindLambert) ? 1u : 0u;
+            n_metal += (alive && ckind == kKindMetal) ? 1u : 0u;
+            n_diel += (alive && ckind == kKindDielectric) ? 1u : 0u;
+        }
 
         // ============ findClosestIntersection + hit handling, all 64 lanes ============
         bool push = false;
@@ -613,7 +621,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 // SampleCount of the surface hit (Surface.fs:20,63,92,115); the single-path estimator takes one child
                 hn = (hinfo >> 2) & 7;
                 if (hinfo & 0x80u) hn = a.lamb;
-                if (a.estimator) hn = min(hn, 1);
+                if (SINGLE) hn = min(hn, 1);
                 // children of a hit at level max_depth+1 are all cut by the depth guard; with a black
                 // background they contribute exactly 0 and are skipped
                 push = hn > 0 && (clevel <= a.max_depth || a.bg_nonzero);
@@ -715,6 +723,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     unsigned long long* stats = ca->stats ? ca->stats + (size_t)(blockIdx.x % kStatsParts) * kStatsWords : nullptr;
     if (stats) {
         const unsigned long long r = nrays, nn = n_nodes, np = n_prims;      // wave-uniform counts
+        if (!BVH) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                n_lamb += __shfl_xor(n_lamb, off); n_metal += __shfl_xor(n_metal, off); n_diel += __shfl_xor(n_diel, off);
+            }
+        }
         float m = maxd;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -742,7 +756,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         }
     }
     if (overflow && lane == 0) atomicOr(ca->status, kStatusOverflow);
-    if (__ballot(range_err) != 0ull && lane == 0) atomicOr(ca->status, kStatusRange);
 }
 
 // Scene.fs:109,114: mean over samples, gamma 2, alpha 1.  One thread per pixel.
