@@ -82,11 +82,16 @@ struct RenderArgs {
     int unused_;
 };
 
-RT_DEV const ColdArgs* cold_args()
+// The pointer stays in the constant address space (the kernarg segment): loads through it are scalar loads of
+// wave-uniform values.  (Through a generic pointer every load counts as divergent for the compiler — a generic address
+// might be lane-private scratch — and with it everything computed from it: the hand-out bounds, the loop conditions,
+// and so the whole render loop was compiled as a divergent loop with its wave-uniform state in vector registers.)
+typedef const ColdArgs __attribute__((address_space(4))) * ColdPtr;
+RT_DEV ColdPtr cold_args()
 {
     uint64_t p = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));     // opaque: plain global loads at the point of use, never hoisted
-    return reinterpret_cast<const ColdArgs*>(p);
+    asm volatile("" : "+s"(p));     // opaque: plain loads at the point of use, never hoisted
+    return (ColdPtr)p;
 }
 
 // bits of the status word a launch leaves behind (rt_scene_status)
@@ -108,6 +113,13 @@ RT_DEV uint32_t make_meta(int slot, int level, int n, int kind, int geom, int su
 {
     return (uint32_t)slot | ((uint32_t)level << 8) | ((uint32_t)n << 13) | ((uint32_t)kind << 16) |
            ((uint32_t)geom << 18) | ((uint32_t)surf << 20);
+}
+
+// the value of the first active lane, as a wave-uniform (scalar) value
+RT_DEV unsigned long long uniform64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 RT_DEV int mbcnt64(unsigned long long m)
@@ -233,15 +245,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     constexpr int PARTS = (PHASE == 2) ? kCounterParts : 1;
     int cur_part = (int)(blockIdx.x % PARTS);
     auto take = [&](int want, unsigned long long total, unsigned long long& base_out) -> int {
-        const ColdArgs* ca = cold_args();
+        const ColdPtr ca = cold_args();
         const unsigned long long per = (total + PARTS - 1) / PARTS;
         while (true) {
             const unsigned long long lo = (unsigned long long)cur_part * per;
             const unsigned long long hi = (lo + per < total) ? lo + per : total;
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(ca->counter + cur_part * kCounterStride, (unsigned long long)want);
-            b = __shfl(b, 0) + lo;
-            if (b < hi) { base_out = b; return (b + (unsigned long long)want <= hi) ? want : (int)(hi - b); }
+            // (readfirstlane, not a shuffle: the compiler then knows the value to be wave-uniform, and with it the loop
+            // conditions that depend on it — otherwise the whole render loop is compiled as a divergent loop)
+            b = uniform64(b) + lo;
+            if (b < hi) { base_out = b; return __builtin_amdgcn_readfirstlane((b + (unsigned long long)want <= hi) ? want : (int)(hi - b)); }
             if (PARTS == 1) return 0;
             // this part is used up: look at all the counters at once for a part with items left, nearest after this one
             unsigned long long cv = ~0ull;
@@ -270,6 +284,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     unsigned long long busymask = 0ull;         // ballot(busy), wave-uniform
 
     while (true) {
+        // The wave-uniform state is passed through readfirstlane once per iteration: free where the compiler already holds
+        // it in scalar registers, and where its analysis had given up (one value it cannot prove uniform makes the exit
+        // condition "divergent", and with it every value carried around the loop) it restores scalar branches and scalar
+        // arithmetic for the bookkeeping of the whole loop (measured: 640x480x1 +6 %, 1M spheres +4 %; the 4K frames of the
+        // linear-scan kernel lose 2 % to the longer scalar dependency chains, so that variant keeps the vector form).
+        if (BVH || PHASE != 0) {
+            top = __builtin_amdgcn_readfirstlane(top); nspill = __builtin_amdgcn_readfirstlane(nspill); base_blk = __builtin_amdgcn_readfirstlane(base_blk);
+            freemask = uniform64(freemask); busymask = uniform64(busymask); res_next = uniform64(res_next);
+            exhausted = __builtin_amdgcn_readfirstlane((int)exhausted) != 0; overflow = __builtin_amdgcn_readfirstlane((int)overflow) != 0;
+            spins = __builtin_amdgcn_readfirstlane(spins);
+        }
         if (top == 0 && nspill > 0) {
             // ---- the LDS part of the pool is consumed: bring back the most recently spilled block
             nspill--;
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         // list has four entries per pixel-sample, in hand-out order (scattered over the image, so neighbours in the
         // list are not neighbours in cost), valid where a child of the primary hit a scattering surface.
         if (PHASE == 2 && nspill == 0 && top <= a.list_low && !exhausted && __popcll(freemask) >= 8) {
-            const ColdArgs* ca = cold_args();
+            const ColdPtr ca = cold_args();
             const int want = min(a.list_chunk, __popcll(freemask));
             unsigned long long base = 0;
             const int n = take(want, (unsigned long long)ca->list_cap, base);
@@ -350,7 +375,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             // expensive pixels while the others have finished
             const int want = min(nfree - nchild, __popcll(freemask));
             if (want > 0) {
-                const ColdArgs* ca = cold_args();
+                const ColdPtr ca = cold_args();
                 unsigned long long base = 0;
                 unsigned long long limit = ca->total;
                 if (PHASE == 1) {
@@ -402,7 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             __syncthreads();
             if (fresh_prim) {
                 // ============ rayTraceBase: primary ray (Camera.fs:8-39, Scene.fs:98-102) ============
-                const ColdArgs* ca = cold_args();
+                const ColdPtr ca = cold_args();
                 slot = (int)map[frank - nchild];
                 const unsigned long long q = res_next + (unsigned long long)(frank - nchild);  // compact index
                 const unsigned long long o64 = q / (unsigned long long)spp;
@@ -550,7 +575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             if (alive && clevel > a.max_depth + 1) {
                 // depth guard (Scene.fs:52-54): the child returns backgroundColor unintersected
                 alive = false;
-                const ColdArgs* ca = cold_args();
+                const ColdPtr ca = cold_args();
                 add_radiance(slot, beta * F3(ca->bg[0], ca->bg[1], ca->bg[2]));
             }
         }
@@ -604,13 +629,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 // cull at TMax/dotView (Plane.fs:46).  A failed re-test is a miss, not the next hit.
                 const uint32_t hg = (hinfo >> 5) & 3;
                 if (is_prim && (hg == kGeomPlaneInf || hg == kGeomPlaneRect)) {
-                    const ColdArgs* ca = cold_args();
+                    const ColdPtr ca = cold_args();
                     const float dot_view = dot(F3(ca->look_n[0], ca->look_n[1], ca->look_n[2]), Dn);   // Scene.fs:76
                     hit = t <= (kTMax / dot_view);
                 }
             }
             if (is_prim && prim_first) {                               // Scene.fs:80 / :29
-                const ColdArgs* ca = cold_args();
+                const ColdPtr ca = cold_args();
                 const uint32_t prim_o = sl_pix[slot];
                 ca->depth[prim_o] = hit ? t : kFltMax;
                 if (ca->ids) ca->ids[prim_o] = hit ? shade[hidx].id : 0ull;
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 push = hn > 0 && (clevel <= a.max_depth || a.bg_nonzero);
                 P = O + Dn * t;                                        // Core.fs:59
             } else if (a.bg_nonzero) {
-                const ColdArgs* ca = cold_args();
+                const ColdPtr ca = cold_args();
                 add_radiance(slot, beta * F3(ca->bg[0], ca->bg[1], ca->bg[2]));
             }
         }
@@ -639,7 +664,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             // its entry of the list in HBM — the hit record if its subtree is to be traced, else stays without children
             // (the meta plane of the list is cleared before the launch: entries of children that never existed)
             if (alive && !busy && clevel == 1 && push) {
-                const ColdArgs* ca = cold_args();
+                const ColdPtr ca = cold_args();
                 const size_t cap = ca->list_cap;
                 const unsigned long long ps = sl_ps[slot];
                 const uint32_t o = sl_pix[slot];
@@ -700,7 +725,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             const int ndone = __popcll(dm);
             if (done) map[mbcnt64(dm)] = (uint32_t)slot;
             __syncthreads();
-            const ColdArgs* ca = cold_args();
+            const ColdPtr ca = cold_args();
             for (int base = 0; base < ndone; base += 16) {
                 const int k = base + (lane >> 2), ch = lane & 3;
                 if (k < ndone && ch < 3) {
@@ -719,7 +744,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     }
 
     // ================= statistics ================================================================
-    const ColdArgs* ca = cold_args();
+    const ColdPtr ca = cold_args();
     unsigned long long* stats = ca->stats ? ca->stats + (size_t)(blockIdx.x % kStatsParts) * kStatsWords : nullptr;
     if (stats) {
         const unsigned long long r = nrays, nn = n_nodes, np = n_prims;      // wave-uniform counts

@@ -28,5 +28,7 @@ def test_no_kernel_spills_vector_registers_to_scratch():
     assert len(trace) == 36, sorted(kernels)          # {NODE64} x {linear, BVH ring 8, BVH ring 16} x {pass 0, 1, 2} x {estimator}
     for name, r in trace.items():
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name, r)
-        bvh = "Lb1ELi" in name.split("trace_kernelILb")[1][1:]
-        assert r["Occupancy [waves/SIMD]"] >= (4 if bvh else 6), (name, r)
+        targs = name.split("trace_kernelILb")[1]
+        bvh, ring16 = targs[2:5] == "Lb1", "ELi16E" in targs
+        # what the launches count on: 22 waves per CU (linear scan), 15-16 (BVH, 8-entry stack ring), 12 (16-entry ring)
+        assert r["Occupancy [waves/SIMD]"] >= ((3 if ring16 else 4) if bvh else 6), (name, r)
