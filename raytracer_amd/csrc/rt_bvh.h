@@ -108,6 +108,16 @@ RT_DEV void sort2(float& ta, uint32_t& ra, float& tb, uint32_t& rb)
 
 constexpr uint32_t kBvhDone = 0xffffffffu;
 
+// Lanes set in a ballot mask, as a 32-bit SCALAR value.  (__popcll of a ballot is a 64-bit value for the compiler, which
+// then compares two such counts with a 64-bit VECTOR compare — there is no scalar one — and from there keeps everything
+// computed from the comparison, the wave-uniform traversal statistics included, in vector registers.)
+RT_DEV int popc_mask(unsigned long long m)
+{
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
+
 // Depth-first traversal, nearest child first, the other hit children on a per-lane stack.  (tmin, idx) come
 // in from the scan of the loose surfaces (planes) and go out updated.
 //
@@ -144,18 +154,20 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         return v;
     };
     while (true) {
-        const bool in = (int)cur >= 0, lf = ((int)cur < 0) & (cur != kBvhDone);
-        const int n_in = __popcll(__ballot(in)), n_lf = __popcll(__ballot(lf));
+        // (a leaf reference is 0x80000000 | first << 3 | count with count >= 1 and first < 2^28: as an int it is below -1 = kBvhDone)
+        const bool in = (int)cur >= 0, lf = (int)cur < -1;
+        const int n_in = popc_mask(__ballot(in)), n_lf = popc_mask(__ballot(lf));
         if (n_in + n_lf == 0 || n_in + n_lf < min_active) break;
-        // a group steps when it is at least leaf_min lanes strong, the larger one in any case
-        const bool do_in = in & ((n_in >= leaf_min) | (n_in >= n_lf));
-        const bool do_leaf = lf & ((n_lf >= leaf_min) | (n_lf > n_in));
-        {   // wave-uniform statistics (kept out of the divergent steps: every lane's copy stays the same)
-            const int c_in = __popcll(__ballot(do_in)), c_lf = __popcll(__ballot(do_leaf));
-            rounds_inner += c_in != 0 ? 1u : 0u;
-            rounds_leaf += c_lf != 0 ? 1u : 0u;
-            nodes_visited += (uint32_t)c_in;
-            prims_tested += (uint32_t)(c_lf + __popcll(__ballot(do_leaf & ((cur & 7u) > 1u))));
+        // a group steps when it is at least leaf_min lanes strong, the larger one in any case (wave-uniform decisions)
+        const bool step_in = (n_in >= leaf_min) | (n_in >= n_lf);
+        const bool step_lf = (n_lf >= leaf_min) | (n_lf > n_in);
+        const bool do_in = in & step_in;
+        const bool do_leaf = lf & step_lf;
+        {   // wave-uniform statistics (scalar arithmetic)
+            rounds_inner += (step_in && n_in != 0) ? 1u : 0u;
+            rounds_leaf += (step_lf && n_lf != 0) ? 1u : 0u;
+            nodes_visited += step_in ? (uint32_t)n_in : 0u;
+            if (step_lf) prims_tested += (uint32_t)n_lf + (uint32_t)popc_mask(__ballot(lf & ((cur & 6u) != 0u)));   // leaves hold 1 or 2
         }
         // Both groups load through the SAME seven 16-byte requests, each lane from its own addresses: a lane at an inner
         // node the six plane vectors and the references of its node, a lane at a leaf its (up to) two records of three

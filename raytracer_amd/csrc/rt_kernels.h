@@ -294,6 +294,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             freemask = uniform64(freemask); busymask = uniform64(busymask); res_next = uniform64(res_next);
             exhausted = __builtin_amdgcn_readfirstlane((int)exhausted) != 0; overflow = __builtin_amdgcn_readfirstlane((int)overflow) != 0;
             spins = __builtin_amdgcn_readfirstlane(spins);
+            nrays = __builtin_amdgcn_readfirstlane(nrays); n_iter = __builtin_amdgcn_readfirstlane(n_iter); n_refill = __builtin_amdgcn_readfirstlane(n_refill);
+            if (BVH) {
+                n_nodes = __builtin_amdgcn_readfirstlane(n_nodes); n_prims = __builtin_amdgcn_readfirstlane(n_prims);
+                n_rin = __builtin_amdgcn_readfirstlane(n_rin); n_rlf = __builtin_amdgcn_readfirstlane(n_rlf);
+                n_lamb = __builtin_amdgcn_readfirstlane(n_lamb); n_metal = __builtin_amdgcn_readfirstlane(n_metal); n_diel = __builtin_amdgcn_readfirstlane(n_diel);
+            }
         }
         if (top == 0 && nspill > 0) {
             // ---- the LDS part of the pool is consumed: bring back the most recently spilled block
