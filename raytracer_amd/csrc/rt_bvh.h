@@ -108,16 +108,6 @@ RT_DEV void sort2(float& ta, uint32_t& ra, float& tb, uint32_t& rb)
 
 constexpr uint32_t kBvhDone = 0xffffffffu;
 
-// Lanes set in a ballot mask, as a 32-bit SCALAR value.  (__popcll of a ballot is a 64-bit value for the compiler, which
-// then compares two such counts with a 64-bit VECTOR compare — there is no scalar one — and from there keeps everything
-// computed from the comparison, the wave-uniform traversal statistics included, in vector registers.)
-RT_DEV int popc_mask(unsigned long long m)
-{
-    int n;
-    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
-    return n;
-}
-
 // Depth-first traversal, nearest child first, the other hit children on a per-lane stack.  (tmin, idx) come
 // in from the scan of the loose surfaces (planes) and go out updated.
 //

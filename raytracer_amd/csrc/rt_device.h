@@ -66,6 +66,25 @@ RT_DEV f3 neg(f3 a) { return F3(-a.x, -a.y, -a.z); }
 RT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 
+// the value of the first active lane, as a wave-uniform (scalar) value
+RT_DEV unsigned long long uniform64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Lanes set in a ballot mask, as a 32-bit SCALAR value.  (__popcll of a ballot is a 64-bit value for the compiler, which
+// then compares two such counts with a 64-bit VECTOR compare — there is no scalar one — and from there keeps everything
+// computed from the comparison, the wave-uniform traversal statistics included, in vector registers.)
+RT_DEV int popc_mask(unsigned long long m)
+{
+    if (__builtin_constant_p(m)) return __builtin_popcountll(m);
+    m = uniform64(m);       // (a no-op for a mask in scalar registers; the compiler may hold a wave-uniform mask in vector ones)
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
+
 // ---- correctly rounded f32 sqrt and divide, normal-range operands --------------------------------
 // hipcc's IEEE lowerings of sqrtf and '/' are v_sqrt_f32 / v_rcp_f32 plus an FMA correction that makes
 // the result correctly rounded, wrapped in scaling code for subnormal operands and results (x < 2^-96,

@@ -115,13 +115,6 @@ RT_DEV uint32_t make_meta(int slot, int level, int n, int kind, int geom, int su
            ((uint32_t)geom << 18) | ((uint32_t)surf << 20);
 }
 
-// the value of the first active lane, as a wave-uniform (scalar) value
-RT_DEV unsigned long long uniform64(unsigned long long v)
-{
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 RT_DEV int mbcnt64(unsigned long long m)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -316,9 +309,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         // list in HBM and put on top of it (here, at the top of the loop, no lane still reads a popped record).  The
         // list has four entries per pixel-sample, in hand-out order (scattered over the image, so neighbours in the
         // list are not neighbours in cost), valid where a child of the primary hit a scattering surface.
-        if (PHASE == 2 && nspill == 0 && top <= a.list_low && !exhausted && __popcll(freemask) >= 8) {
+        if (PHASE == 2 && nspill == 0 && top <= a.list_low && !exhausted && popc_mask(freemask) >= 8) {
             const ColdPtr ca = cold_args();
-            const int want = min(a.list_chunk, __popcll(freemask));
+            const int want = min(a.list_chunk, popc_mask(freemask));
             unsigned long long base = 0;
             const int n = take(want, (unsigned long long)ca->list_cap, base);
             if (n == 0) exhausted = true;
@@ -328,7 +321,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 const uint32_t lmeta = (lane < n) ? lr[(F_META / 64) * cap] : 0u;
                 const bool valid = ((lmeta >> 13) & 7u) != 0u;
                 const unsigned long long vm = __ballot(valid);
-                const int nv = __popcll(vm);
+                const int nv = popc_mask(vm);
                 const bool offer = ((freemask >> lane) & 1ull) != 0 && mbcnt64(freemask) < nv;
                 if (offer) map[mbcnt64(freemask)] = (uint32_t)lane;
                 freemask &= ~__ballot(offer);
@@ -354,7 +347,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         int nchild = 0;
         uint32_t mp = 0u;
         const int top0 = top;
-        const int nfree = BVH ? 64 - __popcll(busymask) : 64;       // lanes that can take a new ray
+        const int nfree = BVH ? 64 - popc_mask(busymask) : 64;       // lanes that can take a new ray
         const int frank = BVH ? mbcnt64(~busymask) : lane;          // rank of this lane among the free lanes
         if (top > 0 && nfree > 0) {
             const int ridx = top - 1 - lane;
@@ -364,12 +357,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             const int excl = mbcnt64(b0) + 2 * mbcnt64(b1) + 4 * mbcnt64(b2);
             const bool take = rn > 0 && excl + rn <= nfree;
             const unsigned long long tk = __ballot(take);
-            nchild = __popcll(b0 & tk) + 2 * __popcll(b1 & tk) + 4 * __popcll(b2 & tk);
+            nchild = popc_mask(b0 & tk) + 2 * popc_mask(b1 & tk) + 4 * popc_mask(b2 & tk);
             if (take)
                 for (int c = 0; c < rn; c++) map[excl + c] = (uint32_t)(lane * 4 + c);
             __syncthreads();
             if (!busy && frank < nchild) mp = map[frank];
-            top -= __popcll(tk);
+            top -= popc_mask(tk);
             __syncthreads();                    // map is reused for the slot allocation below
         }
         RT_FINE(1)   // list install + pop
@@ -379,7 +372,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             // pull exactly as many pixel-samples as there are free lanes (and free slots): one returning
             // atomic per refill keeps the hand-out fine-grained, so no wave is left holding a queue of
             // expensive pixels while the others have finished
-            const int want = min(nfree - nchild, __popcll(freemask));
+            const int want = min(nfree - nchild, popc_mask(freemask));
             if (want > 0) {
                 const ColdPtr ca = cold_args();
                 unsigned long long base = 0;
@@ -590,9 +583,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         // faster than wave-uniform ones, which cost scalar registers the closest-hit loop wants), wave-uniform in the
         // BVH kernels (which have no vector register to spare)
         if (BVH) {
-            n_lamb += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindLambert));
-            n_metal += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindMetal));
-            n_diel += (uint32_t)__popcll(__ballot(!busy && alive && ckind == kKindDielectric));
+            n_lamb += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindLambert));
+            n_metal += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindMetal));
+            n_diel += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindDielectric));
         } else {
             n_lamb += (alive && ckind == kKindLambert) ? 1u : 0u;
             n_metal += (alive && ckind == kKindMetal) ? 1u : 0u;
@@ -609,7 +602,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
             trav_cur = (BVH && bvh.nnodes) ? 0u : kBvhDone; trav_sp = 0; trav_lo = 0;   // BVH: start at the root (an empty tree has none)
         }
-        nrays += (uint32_t)__popcll(__ballot(alive && !busy));
+        nrays += (uint32_t)popc_mask(__ballot(alive && !busy));
         RT_PHASE(ph_scan)
         if (BVH) {
             // new and suspended rays walk the tree together; leave early only when other work can fill the lanes
@@ -664,7 +657,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         }
         // ---- compaction: hits on scattering surfaces become records, deepest on top
         unsigned long long pm = __ballot(push);
-        int npush = __popcll(pm);
+        int npush = popc_mask(pm);
         if (PHASE == 1 && __ballot(alive && !busy && clevel == 1) != 0ull) {
             // ---- first pass of a small frame: every child of a primary that has finished its closest-hit query fills
             // its entry of the list in HBM — the hit record if its subtree is to be traced, else stays without children
@@ -688,7 +681,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             }
             if (clevel == 1) push = false;
             pm = __ballot(push);
-            npush = __popcll(pm);
+            npush = popc_mask(pm);
         }
         if (top + npush > a.nblk * 64) {
             // ---- no room: spill the bottom block of the ring (top >= 64 here, so it is full)
@@ -728,7 +721,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             // does it cooperatively: 4 lanes per finished slot, one per channel, so the three 8-byte adds
             // of a pixel (32-byte aligned) travel as one atomic request instead of three wave-instructions
             // with one lane each (measured: 33 B of HBM write per 8-byte add when issued separately).
-            const int ndone = __popcll(dm);
+            const int ndone = popc_mask(dm);
             if (done) map[mbcnt64(dm)] = (uint32_t)slot;
             __syncthreads();
             const ColdPtr ca = cold_args();
