@@ -66,7 +66,12 @@ def workload_scene(wl):
 # Lambertian child, 60 per Metal child, 110 per Dielectric child and 30 per primary; the kernel counts
 # its rays by kind, so flops per launch = 437 rays + 90 nL + 60 nM + 110 nD + 30 nPrimary.
 FLOPS_SCAN, FLOPS_LAMB, FLOPS_METAL, FLOPS_DIEL, FLOPS_PRIMARY = 437.0, 90.0, 60.0, 110.0, 30.0
-VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 vector (packed FMA); plain f32 ops issue at a quarter of it
+# MI355X_MICROARCH.md: peak FP32 vector.  Measured with tools/valu_ops.hip (profiles/r02_valu_ops.txt): that rate is
+# reached by v_pk_fma_f32 only (two FMAs per lane every ~4.2 cycles: 147 TFLOP/s); a plain v_fma_f32 issues every ~4
+# cycles per SIMD (half the peak), v_add/v_sub/v_mul_f32 every ~2.3 cycles (one flop each: 0.42 of the peak), compares,
+# selects, min/max, conversions and integer multiplies every ~4.1 cycles, v_sqrt/v_rcp every ~8.  The render loop is
+# reference-order arithmetic without contraction, so its own ceiling is well below `peak`.
+VALU_PEAK_TFLOPS = 157.3
 
 
 # BVH scenes: 20 flops per box test (four per visit of a 4-wide node), 40 per triangle test, 27
@@ -85,13 +90,30 @@ def launch_flops(d, wl="c4s"):
     return FLOPS_SCAN * d["rays"] + gen
 
 
+KERNEL_SOURCES = ("rt_kernels.h", "rt_bvh.h", "rt_device.h", "rt_partition.h", "rt_bvh_build.h", "rt_hip.hip")
+
+
+def kernel_sources_sha256():
+    """Identifies the kernels a profile was taken with (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raytracer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def measured_traffic(workload):
     """HBM bytes per launch of rt::trace_kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md); None when that workload was not profiled."""
+    (FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md).  None when that workload was not profiled or when the
+    kernel sources have changed since (profiles/traffic.json records their hash): a stale figure is not reported."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(workload)
-    except OSError:
+            t = json.load(f)
+        if t.get("kernel_sources_sha256") != kernel_sources_sha256():
+            return None
+        return t.get("bytes_per_launch", {}).get(workload)
+    except (OSError, ValueError):
         return None
 
 
@@ -235,7 +257,7 @@ def main():
                          "rays_by_kind": {"lambertian": diag["lamb"], "metal": diag["metal"], "dielectric": diag["diel"],
                                           "primary": diag["rays"] - diag["lamb"] - diag["metal"] - diag["diel"]},
                          "bvh": ({"node_visits_per_ray": diag["nodes"] / max(1, diag["rays"]), "prim_tests_per_ray": diag["prims"] / max(1, diag["rays"]),
-                                  "fetch_GBps": (128.0 * diag["nodes"] + 48.0 * diag["prims"]) / (kern_ms * 1e-3) / 1e9,
+                                  "l1_request_GBps": (128.0 * diag["nodes"] + 48.0 * diag["prims"]) / (kern_ms * 1e-3) / 1e9,   # node and record bytes the lanes ask of L1/L2, not HBM traffic
                                   "inner_rounds": diag["rounds_inner"], "leaf_rounds": diag["rounds_leaf"], "iterations": diag["iters"],
                                   "lanes_per_inner_round": diag["nodes"] / max(1, diag["rounds_inner"]),
                                   "phase_clk_gen_scan_trav_shade": diag["phase_clk"]}

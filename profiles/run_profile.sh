@@ -11,4 +11,4 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_IN
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $OUT/pmc2 -o p -- $CMD > $OUT/pmc2.log 2>&1 || exit 3
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $CMD > $OUT/pmc3.log 2>&1 || exit 4
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o p -- $CMD > $OUT/pmc4.log 2>&1 || exit 5
-find $OUT -name "*.csv" | head -30
+timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d $OUT/pmc5 -o p -- $CMD > $OUT/pmc5.log 2>&1 || exit 6

@@ -38,6 +38,11 @@ for k, d in res["counters"].items():
         lines.append("  VALU busy / wave cycles = %.3f" % (g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")))
     if g("FETCH_SIZE") is not None:
         lines.append("  HBM read  (FETCH_SIZE KB x2 gfx950 correction) = %.1f MB" % (g("FETCH_SIZE") * 2 / 1024))
+    if g("TCC_REQ_sum"):
+        lines.append("  L2 (TCC) hit rate = %.3f, misses / requests = %.3f" % (g("TCC_HIT_sum") / g("TCC_REQ_sum"), g("TCC_MISS_sum") / g("TCC_REQ_sum")))
+    if g("SQ_INSTS_VALU") and g("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
+        lines.append("  cycles per wave64 VALU instruction per SIMD = %.2f" % ((g("GRBM_GUI_ACTIVE") / 8) / (g("SQ_INSTS_VALU") / 1024)))
     if g("WRITE_SIZE") is not None:
         lines.append("  HBM write (WRITE_SIZE KB) = %.1f MB" % (g("WRITE_SIZE") / 1024))
 open(dst + ".txt", "w").write("\n".join(lines) + "\n")
