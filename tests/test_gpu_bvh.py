@@ -102,6 +102,32 @@ def test_find_closest_100k_triangle_mesh():
     assert (m["geom"][idx[idx >= 0]] == abi.GEOM_TRIANGLE).mean() > 0.3
 
 
+def test_find_closest_unit_scale_mesh_from_far_origins():
+    """The slab test's rounding error grows with the ray origin, not with the scene: a mesh one unit across, rays that
+    start ~500 units away (a far camera, or a bounce off a distant plane) and graze it.  Bit-exact against the scan."""
+    m = scenes.heightfield_mesh(64, extent=(-0.5, 0.5, -0.5, 0.5), base=0.0, amplitude=0.2, environment=False)
+    rng = np.random.default_rng(23)
+    n = 40000
+    target = np.stack([rng.uniform(-0.55, 0.55, n), rng.uniform(-0.02, 0.22, n), rng.uniform(-0.55, 0.55, n)], axis=-1)
+    # half of the rays aim a hair inside a triangle next to one of its vertices: vertices are where primitives touch the
+    # faces of their boxes, i.e. where a late entry / early exit of the slab test would lose the hit
+    tri = m["g"][:, :9].astype(np.float64).reshape(-1, 3, 3)
+    pick = rng.integers(0, len(tri), n // 2)
+    vert = tri[pick, rng.integers(0, 3, n // 2)]
+    target[: n // 2] = vert + (tri[pick].mean(axis=1) - vert) * rng.choice([1e-6, 1e-5, 1e-4], (n // 2, 1))
+    v = rng.normal(size=(n, 3))
+    v[:, 1] = np.abs(v[:, 1]) * rng.choice([1.0, 0.02], n)          # half of them nearly horizontal: grazing
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    o = (target + v * rng.uniform(300.0, 900.0, (n, 1))).astype(np.float32)
+    d = (target - o.astype(np.float64))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    s = Scene(surfaces=m)
+    t, idx = s.findClosestIntersection(o, d)
+    rt, ridx = O.find_closest(m, o, d)
+    assert (ridx >= 0).mean() > 0.3
+    assert np.array_equal(idx, ridx) and np.array_equal(t, rt)
+
+
 def test_find_closest_one_million_spheres():
     """config 5's scene at full size: the BVH over 1M spheres against the brute-force scan on 1500 rays."""
     m = scenes.many_spheres(1_000_000)
