@@ -45,22 +45,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // padded): (plane - O) / D is evaluated as fma(plane, 1/D, -O/D).  max/min ignore NaNs (0 * inf when a direction
 // component is 0), which only ever widens the test.  '<= tmax' keeps boxes that can only tie with the
 // current hit: a tie may still win on index.  Empty child slots are boxes at +infinity and always miss.
-// The rounding error of an entry/exit parameter grows with the ray, not with the scene: ~2.4e-7 * (|t| + 2 max|O_k / D_k|)
-// (one ulp of the reciprocal, the roundings of O * inv and of the FMA).  The host pads the boxes for the primitives'
-// own roundings (scene scale); the ray's share is added here as a relative shrink of the entry and an absolute `slack`
-// on the exit, so a far camera or a bounce ray that starts 500 units from a unit-scale mesh cannot lose a hit.
-RT_DEV void box_entry2(v2f nearx, v2f neary, v2f nearz, v2f farx, v2f fary, v2f farz, f3 inv, f3 noi, float tmax, float slack, float& ta, float& tb)
+// The rounding error of a plane parameter grows with the ray, not with the scene: ~2.4e-7 * (|t| + 2 |O_k / D_k|) on
+// axis k (one ulp of the reciprocal, the roundings of O * inv and of the FMA).  The host pads the boxes for the
+// primitives' own roundings (scene scale); the ray's share is applied here, per axis: the near planes are evaluated with
+// -O/D lowered by 1e-6 |O/D| and the far planes with it raised (two addends per axis, prepared once per ray: no
+// instruction per box), and the entry is shrunk by 2e-6 relative before it is compared with the exit.  So a far camera,
+// or a bounce ray that starts 500 units from a unit-scale mesh, cannot lose a hit
+// (tests/test_gpu_bvh.py::test_find_closest_unit_scale_mesh_from_far_origins).  Per axis on purpose: a single slack of
+// max_k |O_k / D_k| accepts every box within reach for a ray with one small direction component (measured: 1M spheres
+// -22 %).
+RT_DEV void box_entry2(v2f nearx, v2f neary, v2f nearz, v2f farx, v2f fary, v2f farz, f3 inv, f3 noi_lo, f3 noi_hi, float tmax, float& ta, float& tb)
 {
     const v2f ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
-    const v2f nx = { noi.x, noi.x }, ny = { noi.y, noi.y }, nz = { noi.z, noi.z };
-    const v2f x0 = __builtin_elementwise_fma(nearx, ix, nx), x1 = __builtin_elementwise_fma(farx, ix, nx);
-    const v2f y0 = __builtin_elementwise_fma(neary, iy, ny), y1 = __builtin_elementwise_fma(fary, iy, ny);
-    const v2f z0 = __builtin_elementwise_fma(nearz, iz, nz), z1 = __builtin_elementwise_fma(farz, iz, nz);
+    const v2f nx = { noi_lo.x, noi_lo.x }, ny = { noi_lo.y, noi_lo.y }, nz = { noi_lo.z, noi_lo.z };
+    const v2f fx = { noi_hi.x, noi_hi.x }, fy = { noi_hi.y, noi_hi.y }, fz = { noi_hi.z, noi_hi.z };
+    const v2f x0 = __builtin_elementwise_fma(nearx, ix, nx), x1 = __builtin_elementwise_fma(farx, ix, fx);
+    const v2f y0 = __builtin_elementwise_fma(neary, iy, ny), y1 = __builtin_elementwise_fma(fary, iy, fy);
+    const v2f z0 = __builtin_elementwise_fma(nearz, iz, nz), z1 = __builtin_elementwise_fma(farz, iz, fz);
     const float tna = fmaxf(fmaxf(x0.x, y0.x), fmaxf(z0.x, 0.0f)), tfa = fminf(fminf(x1.x, y1.x), fminf(z1.x, tmax));
     const float tnb = fmaxf(fmaxf(x0.y, y0.y), fmaxf(z0.y, 0.0f)), tfb = fminf(fminf(x1.y, y1.y), fminf(z1.y, tmax));
-    // conservative per ray: the computed entry may be late and the computed exit early by 2.4e-7 * (|t| + 2 |O/D|) (see `slack`)
-    ta = (tna * 0.999998f <= tfa + slack) ? tna : kFltMax;
-    tb = (tnb * 0.999998f <= tfb + slack) ? tnb : kFltMax;
+    // the |t| share of the rounding error, both sides at once
+    ta = (tna * 0.999998f <= tfa) ? tna : kFltMax;
+    tb = (tnb * 0.999998f <= tfb) ? tnb : kFltMax;
 }
 
 // a x b and a . b with explicit FMAs, in a fixed order (the CPU checker mirrors them with fmaf)
@@ -137,10 +143,8 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     // reciprocal direction for the slab test only (not on the exact path): v_rcp_f32 is enough
     const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
     const f3 noi = F3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
-    // absolute slack of the slab test for this ray (an axis with D_k = 0 has no finite O_k / D_k and is left out: its
-    // planes give infinities or NaNs, which the min/max chain ignores or which only widen the test)
-    const float ax = fabsf(noi.x), ay = fabsf(noi.y), az = fabsf(noi.z);
-    const float slack = 4e-6f * fmaxf(fmaxf(ax < kFltMax ? ax : 0.0f, ay < kFltMax ? ay : 0.0f), az < kFltMax ? az : 0.0f);
+    const f3 noi_lo = F3(noi.x - 1e-6f * fabsf(noi.x), noi.y - 1e-6f * fabsf(noi.y), noi.z - 1e-6f * fabsf(noi.z));
+    const f3 noi_hi = F3(noi.x + 1e-6f * fabsf(noi.x), noi.y + 1e-6f * fabsf(noi.y), noi.z + 1e-6f * fabsf(noi.z));
     // byte offsets, inside a node, of the planes met first / last on each axis (lo.x lo.y lo.z hi.x hi.y hi.z)
     const uint32_t onx = (inv.x < 0.0f) ? 48u : 0u, ony = (inv.y < 0.0f) ? 64u : 16u, onz = (inv.z < 0.0f) ? 80u : 32u;
     const uint32_t ofx = 48u - onx, ofy = 80u - ony, ofz = 112u - onz;
@@ -197,9 +201,9 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             float t0, t1, t2, t3;
             box_entry2(v2f{ nx4.x, nx4.y }, v2f{ ny4.x, ny4.y }, v2f{ nz4.x, nz4.y }, v2f{ fx4.x, fx4.y }, v2f{ fy4.x, fy4.y }, v2f{ fz4.x, fz4.y },
-                       inv, noi, tmin, slack, t0, t1);
+                       inv, noi_lo, noi_hi, tmin, t0, t1);
             box_entry2(v2f{ nx4.z, nx4.w }, v2f{ ny4.z, ny4.w }, v2f{ nz4.z, nz4.w }, v2f{ fx4.z, fx4.w }, v2f{ fy4.z, fy4.w }, v2f{ fz4.z, fz4.w },
-                       inv, noi, tmin, slack, t2, t3);
+                       inv, noi_lo, noi_hi, tmin, t2, t3);
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
             sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
             // the hits are a prefix of the sorted four: descend into the nearest, push the others far to
