@@ -207,6 +207,7 @@ struct Workspace {
 // so the default must not exceed the sample slots of any variant (the kernel makes progress either way, see
 // trace_kernel "leave early", but a larger value only costs occupancy of the lanes)
 constexpr int kMinActiveDefault = 28;
+constexpr int kMinActiveManyLoose = 20;   // scenes that scan 8 or more loose surfaces per ray
 static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slots_of(true, 16), "refill threshold above the sample slots");
 
 // PHASE: 0 = one launch per frame; 1, 2 = the two passes of a small frame (trace_kernel)
@@ -339,7 +340,9 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     a.list_chunk = kListChunk; a.list_low = 16;
     // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
     // 28 of its lanes still walk the tree; a group of lanes steps once 16 of them have gathered
-    a.min_active = p->bvh_min_active > 0 ? p->bvh_min_active : kMinActiveDefault;
+    // (the longer the scan of loose surfaces, the dearer a half-empty generate / scan / shade pass: with the 12 scanned
+    // surfaces of the mixed scene 20 is 1.6 % faster than 28, with the 3 of the mesh and sphere-field scenes 3-5 % slower)
+    a.min_active = p->bvh_min_active > 0 ? p->bvh_min_active : (sc->nloose >= 8 ? kMinActiveManyLoose : kMinActiveDefault);
     a.leaf_min = 16;
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
