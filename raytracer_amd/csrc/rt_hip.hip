@@ -339,11 +339,10 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     // 640x480x1: chunks of 8 / 16 entries 2.0 / 1.2 ms, thresholds 0 / 48 records 0.83 / 1.09 ms against 0.83 ms)
     a.list_chunk = kListChunk; a.list_low = 16;
     // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
-    // 28 of its lanes still walk the tree; a group of lanes steps once 16 of them have gathered
+    // 28 of its lanes still walk the tree (group thresholds of the traversal rounds: rt_bvh.h kBvhInnerMin / kBvhLeafMin)
     // (the longer the scan of loose surfaces, the dearer a half-empty generate / scan / shade pass: with the 12 scanned
     // surfaces of the mixed scene 20 is 1.6 % faster than 28, with the 3 of the mesh and sphere-field scenes 3-5 % slower)
     a.min_active = p->bvh_min_active > 0 ? p->bvh_min_active : (sc->nloose >= 8 ? kMinActiveManyLoose : kMinActiveDefault);
-    a.leaf_min = 16;
     for (int k = 0; k < 3; k++) c.bg[k] = p->background[k];
     // pool bound: 64 records per record level 0..max_trace_depth (+1 with a non-black background)
     // (DESIGN.md "Pool bound"); the top pool_blocks blocks live in LDS, the rest spills to HBM

@@ -71,7 +71,7 @@ struct RenderArgs {
     int max_spill;                  // blocks one wave may spill to HBM (= record levels)
     uint32_t seed_lo, seed_hi;
     int min_active;                 // BVH: leave the traversal when fewer lanes than this are still walking
-    int leaf_min;                   // BVH: lanes that must wait at a leaf before the leaves are tested
+    int unused0_;
     int phase_unused;               // (PHASE is a template parameter of trace_kernel)  0: the whole tree of a pixel-sample in one launch.  Small frames (few pixel-samples,
                                     // each a tree of up to thousands of rays, as much as a wave's whole share) take two:
                                     // 1: the primary rays and their children; the hit records of the children go to a
@@ -79,7 +79,7 @@ struct RenderArgs {
                                     // of starting pixel-samples, so a tree is shared by up to sixteen waves
     int list_chunk, list_low;       // second pass: list entries taken at a time; taken when the pool holds at most list_low records
     int lamb;                       // SampleCount of Lambertian surfaces that do not override it (Surface.fs:63: 4)
-    int unused_;
+    int unused1_;
 };
 
 // The pointer stays in the constant address space (the kernarg segment): loads through it are scalar loads of
@@ -611,8 +611,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             const bool refill = (nchild + nprim > 0) && (top > 0 || nspill > 0 || !exhausted);
             if (!alive) trav_cur = kBvhDone;
             auto backing = [&]() { return cold_args()->gstack + (size_t)blockIdx.x * (kBvhStack * 64) + lane; };
-            closest_hit_bvh<RING, true>(bvh, O, Dn, bvh_stack, 64, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
-                                            refill ? a.min_active : 0, a.leaf_min, n_nodes, n_prims, n_rin, n_rlf);
+            closest_hit_bvh<RING, true, kBvhInnerMin, kBvhLeafMin>(bvh, O, Dn, bvh_stack, 64, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
+                                            refill ? a.min_active : 0, n_nodes, n_prims, n_rin, n_rlf);
             busy = alive && trav_cur != kBvhDone;
             busymask = __ballot(busy);
         }
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __rest
     uint32_t nn = 0, np = 0;
     uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0, lo = 0;
     auto backing = []() -> uint32_t* { return nullptr; };
-    closest_hit_bvh<kBvhStack, false>(bvh, O, D, stack, 1, backing, t, idx, cur, sp, lo, 0, 1, nn, np, nn, np);
+    closest_hit_bvh<kBvhStack, false, 1, 1>(bvh, O, D, stack, 1, backing, t, idx, cur, sp, lo, 0, nn, np, nn, np);
     t_out[i] = t; idx_out[i] = idx;
 }
 
