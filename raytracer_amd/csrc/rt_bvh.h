@@ -159,37 +159,43 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         if (SPILL && sp < lo) { lo = sp; v = backing()[sp * 64]; }
         return v;
     };
-    while (true) {
+    // The loop is software-pipelined: the loads of round r+1 are issued as soon as round r has produced every lane's next
+    // node (`cur`), BEFORE round r's stack pushes and statistics, which then run in the shadow of the memory latency.
+    // (The traversal is latency-bound at 4 waves per SIMD: frame rate is proportional to the waves per CU, so every
+    // instruction taken off the load -> decide -> load chain counts.)
+    bool do_in = false, do_leaf = false;
+    float4 d[7];
+    // decide(): which groups step in the coming round (false: leave the traversal); issue(): their loads
+    auto decide = [&]() -> bool {
         // (a leaf reference is 0x80000000 | first << 3 | count with count >= 1 and first < 2^28: as an int it is below -1 = kBvhDone)
         const bool in = (int)cur >= 0, lf = (int)cur < -1;
         const int n_in = popc_mask(__ballot(in)), n_lf = popc_mask(__ballot(lf));
-        if (n_in + n_lf == 0 || n_in + n_lf < min_active) break;
+        if (n_in + n_lf == 0 || n_in + n_lf < min_active) return false;
         // a group steps when it is at least IN_MIN / LEAF_MIN lanes strong, the larger one in any case (wave-uniform decisions)
         const bool step_in = (n_in >= IN_MIN) | (n_in >= n_lf);
         const bool step_lf = (n_lf >= LEAF_MIN) | (n_lf > n_in);
-        const bool do_in = in & step_in;
-        const bool do_leaf = lf & step_lf;
-        {   // wave-uniform statistics (scalar arithmetic)
-            rounds_inner += (step_in && n_in != 0) ? 1u : 0u;
-            rounds_leaf += (step_lf && n_lf != 0) ? 1u : 0u;
-            nodes_visited += step_in ? (uint32_t)n_in : 0u;
-            if (step_lf) prims_tested += (uint32_t)n_lf + (uint32_t)popc_mask(__ballot(lf & ((cur & 6u) != 0u)));   // leaves hold 1 or 2
-        }
-        // Both groups load through the SAME seven 16-byte requests, each lane from its own addresses: a lane at an inner
-        // node the six plane vectors and the references of its node, a lane at a leaf its (up to) two records of three
-        // float4 — nodes and records share one allocation, so an address is a 32-bit offset from the uniform base.
-        // One set of 28 registers instead of two sets (28 + 24) in flight, seven VMEM instructions per round instead of
-        // thirteen when both groups step.
-        float4 d[7];
-        int cnt = 0;
+        do_in = in & step_in;
+        do_leaf = lf & step_lf;
+        // wave-uniform statistics (scalar arithmetic)
+        rounds_inner += (step_in && n_in != 0) ? 1u : 0u;
+        rounds_leaf += (step_lf && n_lf != 0) ? 1u : 0u;
+        nodes_visited += step_in ? (uint32_t)n_in : 0u;
+        if (step_lf) prims_tested += (uint32_t)n_lf + (uint32_t)popc_mask(__ballot(lf & ((cur & 6u) != 0u)));   // leaves hold 1 or 2
+        return true;
+    };
+    // Both groups load through the SAME seven 16-byte requests, each lane from its own addresses: a lane at an inner
+    // node the six plane vectors and the references of its node, a lane at a leaf its (up to) two records of three
+    // float4 — nodes and records share one allocation, so an address is a 32-bit offset from the uniform base.
+    // One set of 28 registers instead of two sets (28 + 24) in flight, seven VMEM instructions per round instead of
+    // thirteen when both groups step.
+    auto issue = [&]() {
         if (do_in | do_leaf) {
             uint32_t o0, o1;        // inner: the node; leaf: first and second record
             if (do_in) { o0 = cur << 7; o1 = o0; }             // 128 bytes per node; the allocation is < 4 GB (host check)
             else {
                 const uint32_t first = (cur & 0x7fffffffu) >> 3;
-                cnt = (int)(cur & 7u);
                 o0 = bvh.pdata_off + first * 48u;              // 48-byte records
-                o1 = o0 + ((cnt > 1) ? 48u : 0u);
+                o1 = o0 + (((cur & 6u) != 0u) ? 48u : 0u);
             }
             const uint32_t a0 = o0 + (do_in ? onx : 0u), a1 = o0 + (do_in ? ofx : 16u), a2 = o0 + (do_in ? ony : 32u);
             const uint32_t a3 = o1 + (do_in ? ofy : 0u), a4 = o1 + (do_in ? onz : 16u), a5 = o1 + (do_in ? ofz : 32u), a6 = o1 + (do_in ? 96u : 32u);
@@ -198,6 +204,13 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             d[4] = *reinterpret_cast<const float4*>(node_bytes + a4); d[5] = *reinterpret_cast<const float4*>(node_bytes + a5);
             d[6] = *reinterpret_cast<const float4*>(node_bytes + a6);
         }
+    };
+    if (!decide()) return;
+    issue();
+    while (true) {
+        // what this round's inner lanes still have to push once the next loads are under way
+        const bool pushing = do_in;
+        uint32_t p0 = 0u, p1 = 0u, p2 = 0u; int nh = 0;
         if (do_in) {
             // ---- inner node: four slab tests
             const float4 nx4 = d[0], fx4 = d[1], ny4 = d[2], fy4 = d[3], nz4 = d[4], fz4 = d[5], rf = d[6];
@@ -209,31 +222,16 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
                        inv, noi_lo, noi_hi, tmin, t2, t3);
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
             sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
-            // the hits are a prefix of the sorted four: descend into the nearest, push the others far to
-            // near.  Branch-free: three entries are always stored, those beyond the new top are garbage in
-            // free slots (room for three is made first, so they never land on a live entry).
+            // the hits are a prefix of the sorted four: descend into the nearest, push the others far to near (below).
+            // A lane pushes (it has a hit and descends) or pops (it has none), never both in one round.
             const bool h2 = t2 < kFltMax, h3 = t3 < kFltMax;
-            const int nh = (t1 < kFltMax ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
-            if (SPILL && K <= 8) {
-                // (a 16-entry ring has room to spare and its kernel no LDS to spare: it keeps the simpler rule below)
-                // room for exactly the nh entries pushed; the stores beyond the new top go to a dump row behind the
-                // ring (row K), so that they cannot land on a live entry of a full ring.  (Making room for three
-                // whatever nh is cost the 8-entry ring three of its entries: 0.22 TB of spill writes per 4K frame.)
-                while (sp + nh - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
-                stack[((0 < nh) ? (sp & (K - 1)) : K) * stride] = h3 ? r3 : (h2 ? r2 : r1);
-                stack[((1 < nh) ? ((sp + 1) & (K - 1)) : K) * stride] = h3 ? r2 : r1;
-                stack[((2 < nh) ? ((sp + 2) & (K - 1)) : K) * stride] = r1;
-            } else {
-                if (SPILL) while (sp + 3 - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
-                stack[(sp & (K - 1)) * stride] = h3 ? r3 : (h2 ? r2 : r1);
-                stack[((sp + 1) & (K - 1)) * stride] = h3 ? r2 : r1;
-                stack[((sp + 2) & (K - 1)) * stride] = r1;
-            }
-            sp += nh;
+            nh = (t1 < kFltMax ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+            p0 = h3 ? r3 : (h2 ? r2 : r1); p1 = h3 ? r2 : r1; p2 = r1;
             cur = (t0 < kFltMax) ? r0 : pop();
         }
         if (do_leaf) {
             // ---- leaf: test in array order
+            const int cnt = (int)(cur & 7u);
 #pragma unroll
             for (int k = 0; k < kBvhLeafMax; k++) {
                 float t; bool ok;
@@ -245,6 +243,30 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             }
             cur = pop();
         }
+        // ---- next round: decision and loads
+        const bool more = decide();
+        if (more) issue();
+        // ---- this round's pushes.  Branch-free: three entries are always stored, those beyond the new top are garbage in
+        // free slots.
+        if (pushing) {
+            if (SPILL && K <= 8) {
+                // (a 16-entry ring has room to spare and its kernel no LDS to spare: it keeps the simpler rule below)
+                // room for exactly the nh entries pushed; the stores beyond the new top go to a dump row behind the
+                // ring (row K), so that they cannot land on a live entry of a full ring.  (Making room for three
+                // whatever nh is cost the 8-entry ring three of its entries: 0.22 TB of spill writes per 4K frame.)
+                while (sp + nh - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
+                stack[((0 < nh) ? (sp & (K - 1)) : K) * stride] = p0;
+                stack[((1 < nh) ? ((sp + 1) & (K - 1)) : K) * stride] = p1;
+                stack[((2 < nh) ? ((sp + 2) & (K - 1)) : K) * stride] = p2;
+            } else {
+                if (SPILL) while (sp + 3 - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
+                stack[(sp & (K - 1)) * stride] = p0;
+                stack[((sp + 1) & (K - 1)) * stride] = p1;
+                stack[((sp + 2) & (K - 1)) * stride] = p2;
+            }
+            sp += nh;
+        }
+        if (!more) break;
     }
 }
 
