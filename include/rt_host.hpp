@@ -259,6 +259,8 @@ public:
     Vector3 backgroundColor{ 0.0f, 0.0f, 0.0f };                                  // Scene.fs:32
     Vector3 cameraOriginWS{ -3.0f, 6.0f, 15.0f }, lookAt{ -1.0f, 1.0f, -10.0f };   // Scene.fs:36-37
     uint64_t seed = 1; int jitter = 1, device = 0;
+    int estimator = RT_ESTIMATOR_BRANCHING;  // RT_ESTIMATOR_SINGLE_PATH: one child per hit, Dielectric.Scatter (Surface.fs:155-166)
+    int lambertianSamples = 0;               // 0 = Surface.fs:63 (4)
     std::vector<Surface> surfaces;                                                // Scene.fs:33
     std::vector<float> frameBuffer;        // [width][height] Vector4, Scene.fs:28
     std::vector<float> depthBuffer;        // [width][height], Scene.fs:29
@@ -284,6 +286,7 @@ public:
         p.width = width; p.height = height; p.spp = samplesPerPixel; p.max_trace_depth = maxTraceDepth;
         p.background[0] = backgroundColor.X; p.background[1] = backgroundColor.Y; p.background[2] = backgroundColor.Z;
         p.jitter = jitter; p.seed = seed; p.x_begin = 0; p.x_end = width; p.x_step = 1;
+        p.estimator = estimator; p.lambertian_samples = lambertianSamples;
         const int rc = rt_render(sc, &cam, &p, frameBuffer.data(), depthBuffer.data(), objectIds.data(), &maxFrameBufferDepth, &rayCount);
         const std::string err = rc == RT_OK ? "" : rt_last_error();
         rt_scene_destroy(sc);
