@@ -138,7 +138,7 @@ constexpr uint32_t kBvhDone = 0xffffffffu;
 // `cur`/`sp`/`lo` are the lane's traversal state: cur = kBvhDone: no ray, 0: at the root.  The call returns
 // when no lane is walking or fewer than `min_active` are; those continue in the next call.
 template <int K, bool SPILL, int IN_MIN, int LEAF_MIN, typename Backing>
-RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, Backing backing,
+RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, uint32_t* dump, Backing backing,
                             float& tmin, int& idx, uint32_t& cur, int& sp, int& lo, int min_active,
                             uint32_t& nodes_visited, uint32_t& prims_tested, uint32_t& rounds_inner, uint32_t& rounds_leaf)
 {
@@ -251,13 +251,14 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         if (pushing) {
             if (SPILL && K <= 8) {
                 // (a 16-entry ring has room to spare and its kernel no LDS to spare: it keeps the simpler rule below)
-                // room for exactly the nh entries pushed; the stores beyond the new top go to a dump row behind the
-                // ring (row K), so that they cannot land on a live entry of a full ring.  (Making room for three
-                // whatever nh is cost the 8-entry ring three of its entries: 0.22 TB of spill writes per 4K frame.)
+                // room for exactly the nh entries pushed; the stores beyond the new top go to the lane's `dump` word (any
+                // scratch word of LDS: the render kernel lends its lane map, which is rewritten before every use), so
+                // that they cannot land on a live entry of a full ring.  (Making room for three whatever nh is cost the
+                // 8-entry ring three of its entries: 0.22 TB of spill writes per 4K frame.)
                 while (sp + nh - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
-                stack[((0 < nh) ? (sp & (K - 1)) : K) * stride] = p0;
-                stack[((1 < nh) ? ((sp + 1) & (K - 1)) : K) * stride] = p1;
-                stack[((2 < nh) ? ((sp + 2) & (K - 1)) : K) * stride] = p2;
+                *((0 < nh) ? stack + (sp & (K - 1)) * stride : dump) = p0;
+                *((1 < nh) ? stack + ((sp + 1) & (K - 1)) * stride : dump) = p1;
+                *((2 < nh) ? stack + ((sp + 2) & (K - 1)) * stride : dump) = p2;
             } else {
                 if (SPILL) while (sp + 3 - lo > K) { backing()[lo * 64] = stack[(lo & (K - 1)) * stride]; lo++; }
                 stack[(sp & (K - 1)) * stride] = p0;

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             const bool refill = (nchild + nprim > 0) && (top > 0 || nspill > 0 || !exhausted);
             if (!alive) trav_cur = kBvhDone;
             auto backing = [&]() { return cold_args()->gstack + (size_t)blockIdx.x * (kBvhStack * 64) + lane; };
-            closest_hit_bvh<RING, true, kBvhInnerMin, kBvhLeafMin>(bvh, O, Dn, bvh_stack, 64, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
+            closest_hit_bvh<RING, true, kBvhInnerMin, kBvhLeafMin>(bvh, O, Dn, bvh_stack, 64, map + lane, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
                                             refill ? a.min_active : 0, n_nodes, n_prims, n_rin, n_rlf);
             busy = alive && trav_cur != kBvhDone;
             busymask = __ballot(busy);
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __rest
     uint32_t nn = 0, np = 0;
     uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0, lo = 0;
     auto backing = []() -> uint32_t* { return nullptr; };
-    closest_hit_bvh<kBvhStack, false, 1, 1>(bvh, O, D, stack, 1, backing, t, idx, cur, sp, lo, 0, nn, np, nn, np);
+    closest_hit_bvh<kBvhStack, false, 1, 1>(bvh, O, D, stack, 1, stack, backing, t, idx, cur, sp, lo, 0, nn, np, nn, np);
     t_out[i] = t; idx_out[i] = idx;
 }
 
