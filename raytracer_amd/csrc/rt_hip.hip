@@ -739,6 +739,8 @@ int rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* c
     float* f_depth = reinterpret_cast<float*>(reinterpret_cast<char*>(root->d_frame) + fpix * 24);
     std::vector<Staging> st((size_t)nscenes);
     std::vector<int> ncols((size_t)nscenes, 0);
+    uint64_t rays = 0; float maxd = 0.0f;
+    for (int attempt = 0;; attempt++) {
     // 1. every scene starts its share (asynchronous: the devices render concurrently) and queues its placement
     for (int i = 0; i < nscenes; i++) {
         rt_scene* sc = scenes[i];
@@ -770,7 +772,7 @@ int rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* c
         HIP_TRY(hipGetLastError());
     }
     // 2. wait for every share, reduce the scalars (maxFrameBufferDepth: max, Scene.fs:47-48; ray count: sum)
-    uint64_t rays = 0; float maxd = 0.0f;
+    rays = 0; maxd = 0.0f;
     int first_err = RT_OK;
     for (int i = 0; i < nscenes; i++) {
         if (ncols[(size_t)i] <= 0) continue;
@@ -784,7 +786,13 @@ int rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* c
         uint32_t bits = (uint32_t)stats[1]; float m; memcpy(&m, &bits, 4);
         maxd = std::max(maxd, m);
     }
-    if (first_err) return first_err;
+    if (!first_err) break;
+    // a BVH scene's pool capacity is a heuristic (render_on_stream): double it on every handle and render the frame again
+    bool any_bvh = false;
+    for (int i = 0; i < nscenes; i++) any_bvh = any_bvh || scenes[i]->use_bvh;
+    if (first_err != RT_E_OVERFLOW || !any_bvh || attempt >= 3) return first_err;
+    for (int i = 0; i < nscenes; i++) scenes[i]->spill_factor *= 2;
+    }
     // 3. one copy of the gathered frame to the host
     HIP_TRY(hipSetDevice(root->device));
     HIP_TRY(hipMemcpyAsync(rgba, f_rgba, fpix * 16, hipMemcpyDeviceToHost, root->stream));
