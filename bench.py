@@ -253,6 +253,9 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / VALU_PEAK_TFLOPS, "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "kernel": "rt::trace_kernel (+ memsets and rt::resolve_kernel, <1 % of the bracket)",
+                         "peak_note": "157.3 TFLOP/s is v_pk_fma_f32 (measured 147); reference-order f32 arithmetic without "
+                                      "contraction issues v_add/v_mul at ~2.3 and compares/selects/min/max/fma at ~4.1 cycles "
+                                      "per wave64 instruction per SIMD (profiles/r02_valu_ops.txt, DESIGN.md section 6)",
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "flops_per_ray": flops / max(1, diag["rays"]),
                          "rays_by_kind": {"lambertian": diag["lamb"], "metal": diag["metal"], "dielectric": diag["diel"],
                                           "primary": diag["rays"] - diag["lamb"] - diag["metal"] - diag["diel"]},
