@@ -232,15 +232,17 @@ RT_DEV void geom_wait(v16f& lo, v4f& hi) { asm volatile("s_waitcnt lgkmcnt(0)" :
 // surface wins ties; each candidate passes Hitable.Intersect + IntersectionAcceptable(.., 1.0, P).
 // The loop index is wave-uniform: each surface's record sits in SGPRs and costs no vector register.
 // Conditions are combined with '&' so that no short-circuit branch is generated.
+template <bool PREFETCH = true>
 RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D, int& idx_out, float& t_out)
 {
     int idx = -1;
     float tmin = kFltMax;
     v16f r; v4f rh;
-    if (nsurf > 0) { geom_load(geom, r, rh); geom_wait(r, rh); }
+    if (PREFETCH && nsurf > 0) { geom_load(geom, r, rh); geom_wait(r, rh); }
     for (int i = 0; i < nsurf; i++) {
         v16f nr; v4f nrh;
-        geom_load(geom + ((i + 1 < nsurf) ? i + 1 : i), nr, nrh);
+        if (PREFETCH) geom_load(geom + ((i + 1 < nsurf) ? i + 1 : i), nr, nrh);
+        else { geom_load(geom + i, r, rh); geom_wait(r, rh); }
         const int type = __float_as_int(rh[1]);
         float t; bool ok;
         if (type == kGeomSphere) {
@@ -281,8 +283,7 @@ RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D,
         const bool better = ok & (t < tmin);
         tmin = better ? t : tmin;
         idx = better ? __float_as_int(rh[2]) : idx;
-        geom_wait(nr, nrh);
-        r = nr; rh = nrh;
+        if (PREFETCH) { geom_wait(nr, nrh); r = nr; rh = nrh; }
     }
     idx_out = idx; t_out = tmin;
 }

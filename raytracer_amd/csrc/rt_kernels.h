@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         int hn = 0;                             // children of the hit this lane found
         RT_PHASE(ph_gen)
         if (alive && !busy) {
-            closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
+            closest_hit<!BVH>(geom, a.nsurf, O, Dn, hidx, tcur);
             trav_cur = (BVH && bvh.nnodes) ? 0u : kBvhDone; trav_sp = 0; trav_lo = 0;   // BVH: start at the root (an empty tree has none)
         }
         nrays += (uint32_t)popc_mask(__ballot(alive && !busy));
