@@ -232,7 +232,11 @@ RT_DEV void geom_wait(v16f& lo, v4f& hi) { asm volatile("s_waitcnt lgkmcnt(0)" :
 // surface wins ties; each candidate passes Hitable.Intersect + IntersectionAcceptable(.., 1.0, P).
 // The loop index is wave-uniform: each surface's record sits in SGPRs and costs no vector register.
 // Conditions are combined with '&' so that no short-circuit branch is generated.
-template <bool PREFETCH = true>
+// PREFETCH: issue the load of surface i+1 before surface i is evaluated (two records, 40 scalar registers, in flight).
+// It paid in round 1 (19 waves per CU, the loop-carried state of the render loop in vector registers); with 22 waves per
+// CU hiding the scalar-cache latency and the bookkeeping in scalar registers it costs more than it hides: one record at
+// a time is 8.5 % faster on the 4K sphere scene and 5 % on the mixed scene (measured, round 2).  Kept for reference.
+template <bool PREFETCH = false>
 RT_DEV void closest_hit(const GeomRec* __restrict__ geom, int nsurf, f3 O, f3 D, int& idx_out, float& t_out)
 {
     int idx = -1;

@@ -245,7 +245,7 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
         const unsigned long long handouts = phase == 1 ? (c.total + 31) / 32 : (4 * c.total + 31) / 32;
         if (grid > handouts) grid = std::max<unsigned long long>(handouts, 1ull);
     }
-    const size_t wave_spill = (size_t)a.max_spill * NF * 64 * sizeof(uint32_t);
+    const size_t wave_spill = (size_t)c.max_spill * NF * 64 * sizeof(uint32_t);
     const size_t wave_stack = BVH ? (size_t)kBvhStack * 64 * sizeof(uint32_t) : 0;
     if (ws.fixed) {
         // the image does not depend on the number of waves (integer sums): take as many as the scratch holds
@@ -335,9 +335,6 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     c.x_begin = p->x_begin; c.x_step = p->x_step; c.ncols = ncols;
     a.seed_lo = (uint32_t)p->seed; a.seed_hi = (uint32_t)(p->seed >> 32);
     a.lamb = p->lambertian_samples ? p->lambertian_samples : 4;          // Surface.fs:63
-    // second pass of a small frame: 32 list entries at a time, taken when the pool holds at most 16 records (measured on
-    // 640x480x1: chunks of 8 / 16 entries 2.0 / 1.2 ms, thresholds 0 / 48 records 0.83 / 1.09 ms against 0.83 ms)
-    a.list_chunk = kListChunk; a.list_low = 16;
     // measured on the 100k-triangle and 1M-sphere scenes (profiles/README.md): refill the wave when fewer than
     // 28 of its lanes still walk the tree (group thresholds of the traversal rounds: rt_bvh.h kBvhInnerMin / kBvhLeafMin)
     // (the longer the scan of loose surfaces, the dearer a half-empty generate / scan / shade pass: with the 12 scanned
@@ -354,7 +351,7 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     // the level above are still walking: the in-order bound does not hold and the capacity is a heuristic
     // (2x the bound, never seen exceeded); rt_render doubles spill_factor and renders again on RT_E_OVERFLOW.
     // (+1: the second pass of a small frame puts up to 32 list records on top of a pool that still holds up to 16)
-    a.max_spill = (sc->use_bvh ? 2 * sc->spill_factor * levels : levels) + 1;
+    c.max_spill = (sc->use_bvh ? 2 * sc->spill_factor * levels : levels) + 1;
 
     // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
     const float* M = cam->cam_to_world;

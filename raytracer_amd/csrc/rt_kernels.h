@@ -62,24 +62,16 @@ struct ColdArgs {
                                     // order: the four subtrees of one expensive sample lie far apart in the list
     unsigned int list_cap;          // = 4 * total
     unsigned int scatter_inv;       // inverse of `scatter` modulo npix
+    int max_spill;                  // blocks one wave may spill to HBM (= record levels); read on the (rare) spill path only
 };
 
 // Hot constants: live in SGPRs for the whole kernel.
 struct RenderArgs {
     int nsurf, spp, max_depth, bg_nonzero;
     int nblk;                       // 64-record blocks of the pool kept in LDS
-    int max_spill;                  // blocks one wave may spill to HBM (= record levels)
     uint32_t seed_lo, seed_hi;
     int min_active;                 // BVH: leave the traversal when fewer lanes than this are still walking
-    int unused0_;
-    int phase_unused;               // (PHASE is a template parameter of trace_kernel)  0: the whole tree of a pixel-sample in one launch.  Small frames (few pixel-samples,
-                                    // each a tree of up to thousands of rays, as much as a wave's whole share) take two:
-                                    // 1: the primary rays and their children; the hit records of the children go to a
-                                    // list in HBM instead of the pool; 2: the waves pull records from that list instead
-                                    // of starting pixel-samples, so a tree is shared by up to sixteen waves
-    int list_chunk, list_low;       // second pass: list entries taken at a time; taken when the pool holds at most list_low records
     int lamb;                       // SampleCount of Lambertian surfaces that do not override it (Surface.fs:63: 4)
-    int unused1_;
 };
 
 // The pointer stays in the constant address space (the kernarg segment): loads through it are scalar loads of
@@ -104,7 +96,9 @@ constexpr int kStatusRange = 2;         // a radiance contribution was NaN, infi
 // the same moment otherwise queue at one cache line (measured on 640x480x1: 5632 waves x 10 atomics = 0.4 ms per launch).
 constexpr int kCounterParts = 16;       // each counter 128 bytes from the next (its own cache line)
 constexpr int kCounterStride = 16;      // in u64
-constexpr int kListChunk = 32;          // list entries a wave takes at a time in the second pass of a small frame
+constexpr int kListChunk = 32;          // list entries a wave takes at a time in the second pass of a small frame ...
+constexpr int kListLow = 16;            // ... when its pool holds at most this many records (measured on 640x480x1: chunks of
+                                        // 8 / 16 entries 2.0 / 1.2 ms, thresholds 0 / 48 records 0.83 / 1.09 ms against 0.83 ms)
 constexpr int kStatsParts = 128;
 constexpr int kStatsWords = 20;         // == RT_STATS_WORDS (include/rt_abi.h)
 
@@ -221,7 +215,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     bool overflow = false;
     uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
     uint32_t n_lamb = 0, n_metal = 0, n_diel = 0;   // child rays intersected, by the kind that scattered them
-    int spins = 0;
     uint32_t n_refill = 0;                      // hand-outs this wave has taken (two-pass frames)
 #ifdef RT_PHASE_TIMING
     unsigned long long ph_gen = 0, ph_scan = 0, ph_trav = 0, ph_shade = 0, ph_t = __builtin_readcyclecounter();
@@ -290,7 +283,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             top = __builtin_amdgcn_readfirstlane(top); nspill = __builtin_amdgcn_readfirstlane(nspill); base_blk = __builtin_amdgcn_readfirstlane(base_blk);
             freemask = uniform64(freemask); busymask = uniform64(busymask); res_next = uniform64(res_next);
             exhausted = __builtin_amdgcn_readfirstlane((int)exhausted) != 0; overflow = __builtin_amdgcn_readfirstlane((int)overflow) != 0;
-            spins = __builtin_amdgcn_readfirstlane(spins);
             nrays = __builtin_amdgcn_readfirstlane(nrays); n_iter = __builtin_amdgcn_readfirstlane(n_iter); n_refill = __builtin_amdgcn_readfirstlane(n_refill);
             if (BVH) {
                 n_nodes = __builtin_amdgcn_readfirstlane(n_nodes); n_prims = __builtin_amdgcn_readfirstlane(n_prims);
@@ -301,7 +293,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         if (top == 0 && nspill > 0) {
             // ---- the LDS part of the pool is consumed: bring back the most recently spilled block
             nspill--;
-            const uint32_t* src = cold_args()->spill + ((size_t)blockIdx.x * a.max_spill + nspill) * (NF * 64) + lane;
+            const ColdPtr cs = cold_args();
+            const uint32_t* src = cs->spill + ((size_t)blockIdx.x * cs->max_spill + nspill) * (NF * 64) + lane;
             uint32_t* dst = pool + base_blk * (NF * 64) + lane;
 #pragma unroll
             for (int f = 0; f < NF; f++) dst[f * 64] = src[f * 64];
@@ -313,9 +306,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         // list in HBM and put on top of it (here, at the top of the loop, no lane still reads a popped record).  The
         // list has four entries per pixel-sample, in hand-out order (scattered over the image, so neighbours in the
         // list are not neighbours in cost), valid where a child of the primary hit a scattering surface.
-        if (PHASE == 2 && nspill == 0 && top <= a.list_low && !exhausted && popc_mask(freemask) >= 8) {
+        if (PHASE == 2 && nspill == 0 && top <= kListLow && !exhausted && popc_mask(freemask) >= 8) {
             const ColdPtr ca = cold_args();
-            const int want = min(a.list_chunk, popc_mask(freemask));
+            const int want = min(kListChunk, popc_mask(freemask));
             unsigned long long base = 0;
             const int n = take(want, (unsigned long long)ca->list_cap, base);
             if (n == 0) exhausted = true;
@@ -397,7 +390,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 else {
                     res_next = base;
                     nprim = (base + (unsigned long long)want <= limit) ? want : (int)(limit - base);
-                    n_refill += (uint32_t)nprim;
+                    if (PHASE == 1) n_refill += (uint32_t)nprim;
                 }
             }
         }
@@ -405,10 +398,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             if (nspill > 0) continue;           // (cannot happen: a reloaded block always yields children)
             if (exhausted) break;               // nothing in the pool, nothing left to start
             if (PHASE == 2) continue;         // a hand-out without a valid entry (sky, lights): take the next one
-            if (++spins > 4) { overflow = true; break; }   // cannot happen (all slots are free here): never spin
-            continue;
+            overflow = true; break;             // cannot happen (all slots are free here and the hand-out is not used up): never spin
         }
-        n_iter++; spins = 0;
+        n_iter++;
         RT_FINE(2)   // refill atomic
         const bool is_child = !busy && frank < nchild;
         const bool fresh_prim = !busy && !is_child && frank < nchild + nprim;
@@ -603,7 +595,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         int hn = 0;                             // children of the hit this lane found
         RT_PHASE(ph_gen)
         if (alive && !busy) {
-            closest_hit<!BVH>(geom, a.nsurf, O, Dn, hidx, tcur);
+            closest_hit(geom, a.nsurf, O, Dn, hidx, tcur);
             trav_cur = (BVH && bvh.nnodes) ? 0u : kBvhDone; trav_sp = 0; trav_lo = 0;   // BVH: start at the root (an empty tree has none)
         }
         nrays += (uint32_t)popc_mask(__ballot(alive && !busy));
@@ -689,8 +681,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         }
         if (top + npush > a.nblk * 64) {
             // ---- no room: spill the bottom block of the ring (top >= 64 here, so it is full)
-            if (nspill < a.max_spill) {
-                uint32_t* dst = cold_args()->spill + ((size_t)blockIdx.x * a.max_spill + nspill) * (NF * 64) + lane;
+            const ColdPtr cs = cold_args();
+            if (nspill < cs->max_spill) {
+                uint32_t* dst = cs->spill + ((size_t)blockIdx.x * cs->max_spill + nspill) * (NF * 64) + lane;
                 const uint32_t* src = pool + base_blk * (NF * 64) + lane;
 #pragma unroll
                 for (int f = 0; f < NF; f++) dst[f * 64] = src[f * 64];
