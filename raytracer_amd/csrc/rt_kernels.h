@@ -575,18 +575,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             }
         }
 
-        // rays by kind: per-lane counters in the linear-scan kernel (three registers it has to spare; measured 1.3 %
-        // faster than wave-uniform ones, which cost scalar registers the closest-hit loop wants), wave-uniform in the
-        // BVH kernels (which have no vector register to spare)
-        if (BVH) {
-            n_lamb += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindLambert));
-            n_metal += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindMetal));
-            n_diel += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindDielectric));
-        } else {
-            n_lamb += (alive && ckind == kKindLambert) ? 1u : 0u;
-            n_metal += (alive && ckind == kKindMetal) ? 1u : 0u;
-            n_diel += (alive && ckind == kKindDielectric) ? 1u : 0u;
-        }
+        // rays by kind (wave-uniform counts)
+        n_lamb += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindLambert));
+        n_metal += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindMetal));
+        n_diel += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindDielectric));
 
         // ============ findClosestIntersection + hit handling, all 64 lanes ============
         bool push = false;
@@ -773,12 +765,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     unsigned long long* stats = ca->stats ? ca->stats + (size_t)(blockIdx.x % kStatsParts) * kStatsWords : nullptr;
     if (stats) {
         const unsigned long long r = nrays, nn = n_nodes, np = n_prims;      // wave-uniform counts
-        if (!BVH) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                n_lamb += __shfl_xor(n_lamb, off); n_metal += __shfl_xor(n_metal, off); n_diel += __shfl_xor(n_diel, off);
-            }
-        }
         float m = maxd;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
