@@ -23,6 +23,10 @@
 
 using namespace rt;
 static_assert(kStatsWords == RT_STATS_WORDS, "statistics words");
+// layout of a scene's control block (rt_scene::d_ctl), in bytes
+constexpr size_t kCtlCounter = 256, kCtlCounterBytes = sizeof(unsigned long long) * kCounterParts * kCounterStride;
+constexpr size_t kCtlCounter2 = kCtlCounter + kCtlCounterBytes, kCtlStats = kCtlCounter2 + kCtlCounterBytes;
+constexpr size_t kCtlBytes = kCtlStats + sizeof(unsigned long long) * kStatsParts * kStatsWords;
 
 namespace {
 
@@ -131,9 +135,13 @@ struct rt_scene {
     hipStream_t stream = nullptr;              // rt_render / rt_find_closest / rt_render_multi work of this scene
     GeomRec* d_geom = nullptr;
     ShadeRec* d_shade = nullptr;
-    int* d_status = nullptr;
-    unsigned long long* d_statpart = nullptr;  // kStatsParts partial statistics arrays (folded by stats_reduce_kernel)
-    unsigned long long* d_counter = nullptr;   // work counter of the persistent waves
+    // One control block, cleared by one memset per frame (a fill is a launch: a 640x480x1 frame of 0.7 ms paid for six):
+    // status word | hand-out counters of the frame or its first pass | those of the second pass | partial statistics
+    unsigned char* d_ctl = nullptr;
+    int* d_status = nullptr;                   // -> d_ctl
+    unsigned long long* d_counter = nullptr;   // -> d_ctl + kCtlCounter: work counters of the persistent waves
+    unsigned long long* d_counter2 = nullptr;  // -> d_ctl + kCtlCounter2: those of the second pass of a small frame
+    unsigned long long* d_statpart = nullptr;  // -> d_ctl + kCtlStats: kStatsParts partial statistics arrays (folded by resolve_kernel)
     unsigned long long* d_accum = nullptr;     // per-pixel 32.32 radiance sums (grown on demand)
     size_t accum_bytes = 0;
     uint32_t* d_spill = nullptr;               // pool blocks spilled by the persistent waves (grown on demand)
@@ -417,20 +425,18 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     auto launch = [&](auto phase_tag) -> int {
         return p->estimator == RT_ESTIMATOR_SINGLE_PATH ? launch_est(phase_tag, std::true_type()) : launch_est(phase_tag, std::false_type());
     };
-    HIP_TRY(hipMemsetAsync(sc->d_status, 0, sizeof(int), stream));
-    HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long) * kCounterParts * kCounterStride, stream));
+    HIP_TRY(hipMemsetAsync(sc->d_ctl, 0, kCtlBytes, stream));        // status, both sets of counters, partial statistics
     HIP_TRY(hipMemsetAsync(accum, 0, accum_bytes, stream));
-    if (d_stats) HIP_TRY(hipMemsetAsync(sc->d_statpart, 0, sizeof(unsigned long long) * kStatsParts * kStatsWords, stream));
     if (two_pass) {
         rc = launch(std::integral_constant<int, 1>());
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(sc->d_counter, 0, sizeof(unsigned long long) * kCounterParts * kCounterStride, stream));
+        c.counter = sc->d_counter2;
         rc = launch(std::integral_constant<int, 2>());
     } else rc = launch(std::integral_constant<int, 0>());
     if (rc) return rc;
-    if (d_stats) hipLaunchKernelGGL(stats_reduce_kernel, dim3(kStatsWords), dim3(64), 0, stream, sc->d_statpart, reinterpret_cast<unsigned long long*>(d_stats));
-    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, accum, d_rgba,
-                       npix, p->spp);
+    const unsigned pixel_blocks = (unsigned)((npix + 255) / 256);
+    hipLaunchKernelGGL(resolve_kernel, dim3(pixel_blocks + (d_stats ? (unsigned)((kStatsWords + 3) / 4) : 0u)), dim3(256), 0, stream, accum, d_rgba,
+                       npix, p->spp, pixel_blocks, sc->d_statpart, reinterpret_cast<unsigned long long*>(d_stats));
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -622,10 +628,14 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
         if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), nbytes, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(sc->d_nodes) + nbytes, hb.pdata.data(), pbytes, hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_status), sizeof(int));
-    if (e == hipSuccess) e = hipMemset(sc->d_status, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_counter), sizeof(unsigned long long) * kCounterParts * kCounterStride);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_statpart), sizeof(unsigned long long) * kStatsParts * kStatsWords);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_ctl), kCtlBytes);
+    if (e == hipSuccess) e = hipMemset(sc->d_ctl, 0, kCtlBytes);
+    if (e == hipSuccess) {
+        sc->d_status = reinterpret_cast<int*>(sc->d_ctl);
+        sc->d_counter = reinterpret_cast<unsigned long long*>(sc->d_ctl + kCtlCounter);
+        sc->d_counter2 = reinterpret_cast<unsigned long long*>(sc->d_ctl + kCtlCounter2);
+        sc->d_statpart = reinterpret_cast<unsigned long long*>(sc->d_ctl + kCtlStats);
+    }
     if (e == hipSuccess) e = hipDeviceGetAttribute(&sc->num_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) {
         rt_scene_destroy(sc);
@@ -646,9 +656,7 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->stream) { (void)hipStreamSynchronize(sc->stream); (void)hipStreamDestroy(sc->stream); }
     if (sc->d_geom) (void)hipFree(sc->d_geom);
     if (sc->d_shade) (void)hipFree(sc->d_shade);
-    if (sc->d_status) (void)hipFree(sc->d_status);
-    if (sc->d_counter) (void)hipFree(sc->d_counter);
-    if (sc->d_statpart) (void)hipFree(sc->d_statpart);
+    if (sc->d_ctl) (void)hipFree(sc->d_ctl);
     if (sc->d_accum) (void)hipFree(sc->d_accum);
     if (sc->d_spill) (void)hipFree(sc->d_spill);
     if (sc->d_gstack) (void)hipFree(sc->d_gstack);

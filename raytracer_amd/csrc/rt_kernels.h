@@ -794,10 +794,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     if (overflow && lane == 0) atomicOr(ca->status, kStatusOverflow);
 }
 
-// Scene.fs:109,114: mean over samples, gamma 2, alpha 1.  One thread per pixel.
+// Scene.fs:109,114: mean over samples, gamma 2, alpha 1.  One thread per pixel.  The blocks after the last pixel block
+// fold the kStatsParts partial statistics arrays into the caller's (words 1 and 18 are maxima, the others sums), one
+// wave per word: a launch of its own costs a small frame more than the work does.
 __global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* __restrict__ accum, float* __restrict__ rgba,
-                                                      long long npix, int spp)
+                                                      long long npix, int spp, unsigned int pixel_blocks,
+                                                      const unsigned long long* __restrict__ parts, unsigned long long* __restrict__ stats_out)
 {
+    if (blockIdx.x >= pixel_blocks) {
+        const int w = (int)(blockIdx.x - pixel_blocks) * 4 + (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63u);
+        if (w >= kStatsWords) return;
+        const bool is_max = (w == 1 || w == 18);
+        unsigned long long v = 0ull;
+        for (int p = l; p < kStatsParts; p += 64) {
+            const unsigned long long x = parts[(size_t)p * kStatsWords + w];
+            v = is_max ? (x > v ? x : v) : v + x;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long x = __shfl_xor(v, off);
+            v = is_max ? (x > v ? x : v) : v + x;
+        }
+        if (l == 0) stats_out[w] = v;
+        return;
+    }
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= npix) return;
     float c[3];
@@ -825,25 +845,6 @@ __global__ __launch_bounds__(256) void place_columns_kernel(const float* __restr
     *reinterpret_cast<float4*>(f_rgba + 4 * dst) = *reinterpret_cast<const float4*>(rgba + 4 * o);
     f_depth[dst] = depth[o];
     if (ids) f_ids[dst] = ids[o];
-}
-
-// Folds the kStatsParts partial statistics arrays into the caller's (words 1 and 18 are maxima, the others sums).
-// One 64-lane block per word.
-__global__ __launch_bounds__(64) void stats_reduce_kernel(const unsigned long long* __restrict__ parts, unsigned long long* __restrict__ out)
-{
-    const int w = blockIdx.x;
-    const bool is_max = (w == 1 || w == 18);
-    unsigned long long v = 0ull;
-    for (int p = threadIdx.x; p < kStatsParts; p += 64) {
-        const unsigned long long x = parts[(size_t)p * kStatsWords + w];
-        v = is_max ? (x > v ? x : v) : v + x;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long x = __shfl_xor(v, off);
-        v = is_max ? (x > v ? x : v) : v + x;
-    }
-    if (threadIdx.x == 0) out[w] = v;
 }
 
 // findClosestIntersection as a batch query (Surface.fs:49-58): one ray per thread.
