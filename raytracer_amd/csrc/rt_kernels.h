@@ -201,6 +201,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
 
     const int spp = a.spp;
     const unsigned long long t_start = __builtin_readcyclecounter();
+#ifdef RT_WAVE_TIMES
+    const unsigned long long wt_start = wall_clock64();     // 100 MHz, common to the whole device
+#endif
 
     int top = 0;                                // records in the pool (wave-uniform)
     unsigned long long freemask = ~0ull >> (64 - SLOTS);   // free slots (wave-uniform)
@@ -778,6 +781,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
             atomicMax(stats + 18, __builtin_readcyclecounter() - t_start);
+#ifdef RT_WAVE_TIMES
+            if (PHASE == RT_WAVE_TIMES) {   // debug build (tools/wave_times.py): when the waves of one pass start and end
+                const unsigned long long wt_end = wall_clock64();
+                atomicAdd(stats + 12, wt_start); atomicAdd(stats + 13, wt_end);
+                atomicMax(stats + 14, ~wt_start); atomicMax(stats + 15, wt_start);
+                atomicMax(stats + 16, ~wt_end); atomicMax(stats + 17, wt_end);
+                atomicAdd(stats + 19, 1ull);
+            }
+#endif
             if (BVH) {
                 atomicAdd(stats + 8, nn); atomicAdd(stats + 9, np);
                 atomicAdd(stats + 10, (unsigned long long)n_rin); atomicAdd(stats + 11, (unsigned long long)n_rlf);
@@ -804,7 +816,11 @@ __global__ __launch_bounds__(256) void resolve_kernel(const unsigned long long* 
     if (blockIdx.x >= pixel_blocks) {
         const int w = (int)(blockIdx.x - pixel_blocks) * 4 + (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63u);
         if (w >= kStatsWords) return;
+#ifdef RT_WAVE_TIMES
+        const bool is_max = (w == 1 || w == 18 || (w >= 14 && w <= 17));
+#else
         const bool is_max = (w == 1 || w == 18);
+#endif
         unsigned long long v = 0ull;
         for (int p = l; p < kStatsParts; p += 64) {
             const unsigned long long x = parts[(size_t)p * kStatsWords + w];
