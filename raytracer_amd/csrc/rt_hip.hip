@@ -157,8 +157,8 @@ struct rt_scene {
     uint32_t pdata_off = 0;                    // byte offset of the records
     int nnodes = 0, bvh_depth = 0;
     int64_t nprims = 0;                        // primitives in the BVH
-    int occ_smem[24] = { 0 };         // (0 = not queried yet) LDS size the cached occupancy below was queried for (per kernel variant)
-    int occ_per_cu[24] = { 0 };
+    int occ_smem[32] = { 0 };         // (0 = not queried yet) LDS size the cached occupancy below was queried for (per kernel variant)
+    int occ_per_cu[32] = { 0 };
     unsigned char* d_list = nullptr;    // small frames: hit records of the primary pass (grown on demand)
     size_t list_bytes = 0;
     float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
@@ -218,7 +218,17 @@ constexpr int kMinActiveDefault = 28;
 constexpr int kMinActiveManyLoose = 20;   // scenes that scan 8 or more loose surfaces per ray
 static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slots_of(true, 16), "refill threshold above the sample slots");
 
-// PHASE: 0 = one launch per frame; 1, 2 = the two passes of a small frame (trace_kernel)
+#ifndef RT_SAMPLE_MAJOR_BELOW
+#define RT_SAMPLE_MAJOR_BELOW 16384
+#endif
+#ifndef RT_BVH_GROUP_SHIFT
+#define RT_BVH_GROUP_SHIFT 2
+#endif
+constexpr int kBvhGroupShift = RT_BVH_GROUP_SHIFT;
+constexpr int kDeepTrace = 8;           // maxTraceDepth above which the samples of a pixel are not kept together (launch_trace)
+constexpr long long kSampleMajorBelow = RT_SAMPLE_MAJOR_BELOW;   // pixel-samples per wave below which a one-pass frame is handed out sample-major
+
+// PHASE: 0 = one launch per frame; 1, 2 = the two passes of a small frame; 3 = one launch, handed out sample-major (trace_kernel)
 // SINGLE: the single-path estimator (rt_params.estimator)
 template <bool NODE64, bool BVH, int RING, int PHASE, bool SINGLE>
 int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_cu,
@@ -228,7 +238,7 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
     const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING, PHASE, SINGLE>);
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     // the attribute and the occupancy query cost host time: once per (kernel, LDS size) and scene
-    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE + (SINGLE ? 12 : 0);
+    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE + (SINGLE ? 16 : 0);
     int& cached_smem = sc->occ_smem[variant];
     int& cached_per_cu = sc->occ_per_cu[variant];
     if (cached_smem != (int)smem) {
@@ -243,7 +253,7 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
     // persistent waves: no more than fit on the chip, no more than there are 64-sample refills
     const unsigned long long chunks = (c.total + 63) / 64;
     unsigned long long grid = (unsigned long long)per_cu * (unsigned long long)sc->num_cus;
-    if (phase == 0) {
+    if (phase == 0 || phase == 3) {
         // Frames that are small for the chip but too large for the two-pass scheme: with one refill per wave there is
         // no dynamic balancing left and the waves that drew expensive pixels finish alone.  Two thirds as many waves
         // as refills balances better (measured on 640x480x1 before it became a two-pass frame: 13.8 -> 15.0 Grays/s).
@@ -276,6 +286,16 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
             c.gstack = sc->d_gstack;
         }
     }
+    // hand-out order of a sample-major one-pass frame (PHASE 3; rt_kernels.h, primary ray)
+    // Samples of one pixel that stay together.  Measured (A/B on one box, G = 1 / 2 / 4 against the pixel-major order):
+    // 800x640x16 linear scan +1.5 % with G = 1 (the tail shrinks from 0.77 to 0.18 ms, but the bulk of the frame gets
+    // 6 % slower: the rays of an iteration no longer hit the same kinds of surface, and the three scatter routines
+    // diverge); 100k-triangle mesh, 16 spp, depth 5: -1.5 / -0.7 / 0 % (coherent primaries are worth what the balance
+    // gains); 1M spheres, 4 spp, depth 16: +7 / +4.5 / 0 % (trees of thousands of rays under a few pixels).  Hence:
+    // no grouping in the linear-scan kernel and for deep traces, groups of 4 in the BVH kernels otherwise.
+    c.group_shift = 0;
+    if (BVH && a.max_depth <= kDeepTrace)
+        while (c.group_shift < kBvhGroupShift && a.spp % (2 << c.group_shift) == 0) c.group_shift++;
     hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING, PHASE, SINGLE>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
                        bvh_ref(sc));
     HIP_TRY(hipGetLastError());
@@ -432,6 +452,10 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
         if (rc) return rc;
         c.counter = sc->d_counter2;
         rc = launch(std::integral_constant<int, 2>());
+    } else if (c.total < (unsigned long long)kSampleMajorBelow * 16ull * (unsigned long long)sc->num_cus) {
+        // a wave's share of the frame is small enough for one heavy refill to matter: sample-major hand-out (4K frames
+        // keep the samples of a pixel together: they meet in the pixel cache, and their tail is under 1 % of the frame)
+        rc = launch(std::integral_constant<int, 3>());
     } else rc = launch(std::integral_constant<int, 0>());
     if (rc) return rc;
     const unsigned pixel_blocks = (unsigned)((npix + 255) / 256);

@@ -63,6 +63,9 @@ struct ColdArgs {
     unsigned int list_cap;          // = 4 * total
     unsigned int scatter_inv;       // inverse of `scatter` modulo npix
     int max_spill;                  // blocks one wave may spill to HBM (= record levels); read on the (rare) spill path only
+    int group_shift;                // PHASE 3 (one-pass frame handed out sample-major): hand-out position q =
+                                    // ((sample / G) * npix + pixel position) * G + sample % G with G = 1 << group_shift (a divisor
+                                    // of spp) instead of pixel position * spp + sample (see the primary ray in trace_kernel)
 };
 
 // Hot constants: live in SGPRs for the whole kernel.
@@ -428,8 +431,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 const ColdPtr ca = cold_args();
                 slot = (int)map[frank - nchild];
                 const unsigned long long q = res_next + (unsigned long long)(frank - nchild);  // compact index
-                const unsigned long long o64 = q / (unsigned long long)spp;
-                const int s = (int)(q - o64 * (unsigned long long)spp);
+                // Which pixel-sample position q is.  Large frames: consecutive positions are the samples of one pixel
+                // (they meet in the pixel cache of the flush).  Frames with few refills per wave (PHASE 3): consecutive
+                // positions are the same sample of pixels far apart — a refill of 32 neighbouring samples is 32 ray trees
+                // of the same size, and when they are floor pixels (thousands of rays each) that one refill is as much
+                // work as a wave's whole fair share of an 800x640x16 frame: measured with tools/wave_times.py, the last
+                // wave of that frame ended 0.77 ms after the counter ran out (10 % of the frame; 9 % on the mesh frame,
+                // 15 % on the 1M-sphere frame).
+                // Between the two, G samples of a pixel stay together (the BVH kernels: neighbouring primaries walk the
+                // tree together, which is worth more there than the last bit of balance).
+                constexpr bool smajor = PHASE == 3;
+                const int gs = smajor ? ca->group_shift : 0;
+                const unsigned long long qt = q >> gs;
+                const unsigned long long qdiv = smajor ? (unsigned long long)ca->npix : (unsigned long long)spp;
+                const unsigned long long qq = qt / qdiv, qr = qt - qq * qdiv;
+                const unsigned long long o64 = smajor ? qr : qq;
+                const int s = smajor ? (int)(qq << gs) + (int)(q & ((1ull << gs) - 1ull)) : (int)qr;
                 // Consecutive hand-outs go to pixels far apart in the image (a fixed bijection), so that every
                 // refill mixes cheap and expensive pixels: with row-major hand-out one wave would start on 64
                 // neighbouring floor pixels (thousands of rays each) and finish long after the others.

@@ -25,7 +25,7 @@ def test_no_kernel_spills_vector_registers_to_scratch():
         if m and cur:
             kernels[cur][m.group(1)] = int(m.group(2))
     trace = {k: v for k, v in kernels.items() if "trace_kernel" in k}
-    assert len(trace) == 36, sorted(kernels)          # {NODE64} x {linear, BVH ring 8, BVH ring 16} x {pass 0, 1, 2} x {estimator}
+    assert len(trace) == 48, sorted(kernels)          # {NODE64} x {linear, BVH ring 8, BVH ring 16} x {pass 0, 1, 2, 3} x {estimator}
     for name, r in trace.items():
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] == 0, (name, r)
         targs = name.split("trace_kernelILb")[1]

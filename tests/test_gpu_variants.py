@@ -129,6 +129,15 @@ def test_two_pass_frames_equal_one_pass_frames_and_the_oracle(kw, mesh):
     assert np.array_equal(a.depthBuffer, b.depthBuffer) and a.rayCount == b.rayCount
 
 
+@pytest.mark.parametrize("spp,depth,mesh", [(4, 3, True), (6, 3, True), (16, 2, True), (4, 9, True), (16, 3, False), (3, 4, False)])
+def test_one_pass_hand_out_orders(spp, depth, mesh):
+    """One-pass frames with few refills per wave are handed out sample-major, the BVH kernels keeping groups of 4, 2 or 1
+    samples of a pixel together (by the divisors of spp; no groups above maxTraceDepth 8): every order must give the
+    oracle's frame and ray count."""
+    _compare(Scene(surfaces=_mixed(10) if mesh else None, width=40, height=28, samplesPerPixel=spp, maxTraceDepth=depth,
+                   jitter=1, seed=21, two_pass=1, lambertian_samples=2 if depth > 4 else 0))
+
+
 def test_two_pass_column_partition_and_empty_regions():
     """Interleaved columns of a two-pass frame equal the full frame; a scene that is mostly sky (list chunks without a
     single valid entry) terminates with the right image."""
