@@ -225,6 +225,10 @@ static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slo
 #define RT_BVH_GROUP_SHIFT 2
 #endif
 constexpr int kBvhGroupShift = RT_BVH_GROUP_SHIFT;
+#ifndef RT_LIN_GROUP_SHIFT
+#define RT_LIN_GROUP_SHIFT 2
+#endif
+constexpr int kLinGroupShift = RT_LIN_GROUP_SHIFT;
 constexpr int kDeepTrace = 8;           // maxTraceDepth above which the samples of a pixel are not kept together (launch_trace)
 constexpr long long kSampleMajorBelow = RT_SAMPLE_MAJOR_BELOW;   // pixel-samples per wave below which a one-pass frame is handed out sample-major
 
@@ -287,15 +291,15 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
         }
     }
     // hand-out order of a sample-major one-pass frame (PHASE 3; rt_kernels.h, primary ray)
-    // Samples of one pixel that stay together.  Measured (A/B on one box, G = 1 / 2 / 4 against the pixel-major order):
-    // 800x640x16 linear scan +1.5 % with G = 1 (the tail shrinks from 0.77 to 0.18 ms, but the bulk of the frame gets
-    // 6 % slower: the rays of an iteration no longer hit the same kinds of surface, and the three scatter routines
-    // diverge); 100k-triangle mesh, 16 spp, depth 5: -1.5 / -0.7 / 0 % (coherent primaries are worth what the balance
-    // gains); 1M spheres, 4 spp, depth 16: +7 / +4.5 / 0 % (trees of thousands of rays under a few pixels).  Hence:
-    // no grouping in the linear-scan kernel and for deep traces, groups of 4 in the BVH kernels otherwise.
+    // Samples of one pixel that stay together, G = 1 << group_shift.  Measured (A/B on one box, against the pixel-major
+    // order): 800x640x16 linear scan +2.4 / +3.6 / +4.6 / +2.6 % with G = 1 / 2 / 4 / 8 (with G = 1 the tail shrinks
+    // from 0.77 to 0.18 ms, but the bulk of the frame gets 6 % slower: the rays of an iteration no longer hit the same
+    // kinds of surface, and the three scatter routines diverge); 100k-triangle mesh, 16 spp, depth 5: -1.5 / -0.7 /
+    // +0.8 % with G = 1 / 2 / 4 (coherent primaries are worth what the balance gains); 1M spheres, 4 spp, depth 16:
+    // +7 / +4.5 / 0 % (trees of thousands of rays under a few pixels).  Hence groups of 4, none for deep traces.
     c.group_shift = 0;
-    if (BVH && a.max_depth <= kDeepTrace)
-        while (c.group_shift < kBvhGroupShift && a.spp % (2 << c.group_shift) == 0) c.group_shift++;
+    if (a.max_depth <= kDeepTrace)
+        while (c.group_shift < (BVH ? kBvhGroupShift : kLinGroupShift) && a.spp % (2 << c.group_shift) == 0) c.group_shift++;
     hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING, PHASE, SINGLE>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
                        bvh_ref(sc));
     HIP_TRY(hipGetLastError());

@@ -131,7 +131,7 @@ def test_two_pass_frames_equal_one_pass_frames_and_the_oracle(kw, mesh):
 
 @pytest.mark.parametrize("spp,depth,mesh", [(4, 3, True), (6, 3, True), (16, 2, True), (4, 9, True), (16, 3, False), (3, 4, False)])
 def test_one_pass_hand_out_orders(spp, depth, mesh):
-    """One-pass frames with few refills per wave are handed out sample-major, the BVH kernels keeping groups of 4, 2 or 1
+    """One-pass frames with few refills per wave are handed out sample-major, keeping groups of 4, 2 or 1
     samples of a pixel together (by the divisors of spp; no groups above maxTraceDepth 8): every order must give the
     oracle's frame and ray count."""
     _compare(Scene(surfaces=_mixed(10) if mesh else None, width=40, height=28, samplesPerPixel=spp, maxTraceDepth=depth,
