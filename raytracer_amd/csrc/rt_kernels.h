@@ -52,7 +52,7 @@ struct ColdArgs {
     float* depth;                   // [ncols*H]
     unsigned long long* ids;        // [ncols*H] or null
     unsigned long long* stats;      // [kStatsParts][RT_STATS_WORDS] partial sums (wave w adds to part w % kStatsParts;
-                                    // stats_reduce_kernel folds them into the caller's array), or null
+                                    // resolve_kernel folds them into the caller's array), or null
     int* status;                    // overflow flag
     uint32_t* spill;                // [waves][max_spill][NF*64] pool blocks spilled to HBM
     uint32_t* gstack;               // [waves][kBvhStack][64] backing store of the traversal stacks (BVH)
