@@ -2,7 +2,7 @@
 # tools/sweep_flag.sh "<workloads>" <bench flag> "<values>"
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out
 for wl in $1; do for v in $3; do
-  timeout -k 10 120 python3 $R/bench.py --workload $wl --steps 2 --warmup 1 --no-extra --no-cpu-baseline $2 $v > $OUT/sw_${wl}_$v.log 2>&1 || exit 1
+  timeout -k 10 120 python3 $R/bench.py --workload $wl --steps ${STEPS:-2} --warmup 1 --no-extra --no-cpu-baseline $2 $v > $OUT/sw_${wl}_$v.log 2>&1 || exit 1
   python3 - $OUT/sw_${wl}_$v.log $wl "$2 $v" <<'PY'
 import json,sys
 for l in open(sys.argv[1]):
