@@ -249,6 +249,14 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int q = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 64, smem));
+        // The query over-states what is resident: LDS is handed out in granules of 1 280 bytes (measured with
+        // tools/launch_ramp.hip: 6 400 B per wave -> 25 waves per CU, 6 656 .. 7 680 B -> 21, 7 936 B -> 18), so the
+        // 7 168 B of the linear-scan kernel put 21 waves on a CU, not the 22 the query reports.  A 22nd wave per CU
+        // starts when another ends: harmless in a long frame, but the first pass of a small frame (waves of 45 us)
+        // then runs as two generations.
+        constexpr size_t kLdsPerCu = 160 * 1024, kLdsGranule = 1280;
+        const int fit = (int)(kLdsPerCu / ((smem + kLdsGranule - 1) / kLdsGranule * kLdsGranule));
+        if (q > fit) q = fit;
         cached_per_cu = q < 1 ? 1 : q;
         cached_smem = (int)smem;
     }
