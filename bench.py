@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the render loop on N MI355X (one process per GPU).
 
+`python bench.py --gpus N` works with or without a launcher: under torch.distributed.run (WORLD_SIZE set) this process
+is one rank; started plainly with N > 1 it becomes the parent of N fresh rank processes (raytracer_amd/launch.py).
+
 A "step" is one full frame of the workload: every rank renders its interleaved image columns with
 the HIP kernel (device buffers, no PCIe in the timed region), the framebuffer and depth buffer are
 gathered to rank 0 over RCCL/xGMI, and ray count / max depth are all-reduced.  The frame is fixed
@@ -14,6 +17,7 @@ Workloads (BASELINE.json configs; camera of Scene.fs:36-43 unless noted):
   c2   scene_spheres, 800x640, 16 spp, maxTraceDepth 4, jitter on    — configs[1]
   c1   scene_spheres, 640x480, 1 spp, maxTraceDepth 5, pinhole       — configs[0]
   c3   100k-triangle mesh + floor + lights, 800x640, 16 spp, maxTraceDepth 5     — configs[2], BVH
+  c3_1 the same at 1 spp ("spp 1 & 16")
   c5   1M spheres + floor + lights, 1920x1080, 4 spp, maxTraceDepth 16, Lambertian SampleCount 1 — configs[4], BVH
 """
 import argparse
@@ -30,6 +34,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 WORKLOADS = {
     "c4": dict(width=3840, height=2160, samplesPerPixel=64, maxTraceDepth=5, jitter=1, seed=1),
     "c3": dict(width=800, height=640, samplesPerPixel=16, maxTraceDepth=5, jitter=1, seed=1),
+    "c3_1": dict(width=800, height=640, samplesPerPixel=1, maxTraceDepth=5, jitter=1, seed=1),      # "spp 1 & 16"
     "c5": dict(width=1920, height=1080, samplesPerPixel=4, maxTraceDepth=16, jitter=1, seed=1, lambertian_samples=1),
     "c4s": dict(width=3840, height=2160, samplesPerPixel=64, maxTraceDepth=5, jitter=1, seed=1),
     "c2": dict(width=800, height=640, samplesPerPixel=16, maxTraceDepth=4, jitter=1, seed=1),
@@ -37,6 +42,7 @@ WORKLOADS = {
 }
 
 SCENE_NAMES = {"c4": "scene_spheres + 100352-triangle mesh (BVH)", "c3": "100352-triangle mesh + floor + 2 lights (BVH)",
+               "c3_1": "100352-triangle mesh + floor + 2 lights (BVH)",
                "c5": "1M spheres + floor + 2 lights (BVH)"}
 _scene_cache = {}
 
@@ -46,7 +52,7 @@ def workload_scene(wl):
     import numpy as np
     from raytracer_amd import abi, host, scenes
     if wl not in _scene_cache:
-        if wl == "c3":
+        if wl in ("c3", "c3_1"):
             _scene_cache[wl] = (scenes.heightfield_mesh(224), {})
         elif wl == "c4":
             arr = host.flatten_surfaces(host.SceneDefinitions.scene_spheres)
@@ -72,12 +78,15 @@ FLOPS_SCAN, FLOPS_LAMB, FLOPS_METAL, FLOPS_DIEL, FLOPS_PRIMARY = 437.0, 90.0, 60
 # selects, min/max, conversions and integer multiplies every ~4.1 cycles, v_sqrt/v_rcp every ~8.  The render loop is
 # reference-order arithmetic without contraction, so its own ceiling is well below `peak`.
 VALU_PEAK_TFLOPS = 157.3
+PEAK_NOTE = ("157.3 TFLOP/s is v_pk_fma_f32 (measured 147); reference-order f32 arithmetic without "
+             "contraction issues v_add/v_mul at ~2.3 and compares/selects/min/max/fma at ~4.1 cycles "
+             "per wave64 instruction per SIMD (profiles/r02_valu_ops.txt, DESIGN.md section 6)")
 
 
 # BVH scenes: 20 flops per box test (four per visit of a 4-wide node), 40 per triangle test, 27
 # per sphere test, plus the surfaces scanned per ray (planes; in c4 also the 6 spheres of scene_spheres, which a mesh
 # scene keeps out of the tree); bytes: 128 per node visit, 48 per primitive record.
-BVH_COST = {"c3": dict(scan=19.0 + 2 * 44.0, prim=40.0), "c4": dict(scan=FLOPS_SCAN, prim=40.0),
+BVH_COST = {"c3": dict(scan=19.0 + 2 * 44.0, prim=40.0), "c3_1": dict(scan=19.0 + 2 * 44.0, prim=40.0), "c4": dict(scan=FLOPS_SCAN, prim=40.0),
             "c5": dict(scan=19.0 + 2 * 44.0, prim=27.0)}
 
 
@@ -141,7 +150,7 @@ def cpu_baseline():
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -153,24 +162,52 @@ def main():
     ap.add_argument("--bvh-min-active", type=int, default=0, help="tuning: refill threshold of the BVH kernels (0 = 28)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend for --gpus N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    from raytracer_amd import launch
+    if args.gpus > 1 and not launch.launched_as_rank():
+        # Started without a launcher (`python bench.py --gpus N`): this process becomes the parent of N fresh rank
+        # processes and never touches the GPU itself (no torch import here, no exec).
+        sys.exit(launch.relaunch_self(args.gpus, os.path.abspath(__file__)))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` "
+              f"or under torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi, multi
     from raytracer_amd.scene import Scene
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    share_one_gpu = args.backend == "gloo"          # rehearsal: every rank on device 0, gloo instead of RCCL
+    ndev = torch.cuda.device_count()                # (counting devices does not initialise the GPU)
+    need = 1 if share_one_gpu else world
+    if ndev < need:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} needs {need} visible GPU(s), this box has {ndev}: nothing was run "
+                  "(the render path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    if share_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    gdev = torch.device("cpu") if share_one_gpu else dev     # where the gathered frame lives
 
     def barrier():
         if world > 1:
@@ -183,14 +220,20 @@ def main():
         cfg.update(extra_kw)
         sc = Scene(surfaces=surfaces, device=local_rank, waves_per_cu=args.waves_per_cu, pool_blocks=args.pool_blocks,
                    bvh_ring=args.bvh_ring, bvh_min_active=args.bvh_min_active, **cfg)
+        t0 = time.perf_counter()
+        sc.upload()                                   # rt_scene_create: flatten, host BVH build, upload (once per scene)
+        create_ms = (time.perf_counter() - t0) * 1e3
         xb, xe, xs, ncols = multi.columns_of_rank(sc.width, rank, world)
-        bufs = dict(
-            rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
-            depth=torch.zeros((ncols, sc.height), dtype=torch.float32, device=dev),
-            stats=torch.zeros(abi.RT_STATS_WORDS, dtype=torch.int64, device=dev),
-        )
-        g = multi.FrameGatherer(sc.width, sc.height, dev, rank, world)
-        return sc, (xb, xe, xs), bufs, g
+        g = multi.FrameGatherer(sc.width, sc.height, gdev, rank, world)
+        if share_one_gpu:
+            bufs = dict(rgba=torch.zeros((ncols, sc.height, 4), dtype=torch.float32, device=dev),
+                        depth=torch.zeros((ncols, sc.height), dtype=torch.float32, device=dev))
+        else:
+            # the kernel renders straight into the gather's send buffers
+            r, d, _ = g.render_targets()
+            bufs = dict(rgba=r, depth=d)
+        bufs["stats"] = torch.zeros(abi.RT_STATS_WORDS, dtype=torch.int64, device=dev)
+        return sc, (xb, xe, xs), bufs, g, create_ms
 
     diag = {}
 
@@ -211,14 +254,22 @@ def main():
         diag["phase_clk"] = [int(st[i].item()) for i in (12, 13, 14, 15)]
         diag["max_wave_clk"] = int(st[18].item())
         maxd = torch.tensor([int(st[1].item()) & 0xffffffff], dtype=torch.int64).view(torch.float32)[0].item()
-        return g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
+        if ev:
+            ev[2].record()
+        if share_one_gpu:
+            out = g.gather(bufs["rgba"].cpu(), bufs["depth"].cpu(), None, rays, maxd)
+        else:
+            out = g.gather(bufs["rgba"], bufs["depth"], None, rays, maxd)
+        if ev:
+            ev[3].record()
+        return out
 
     def run(wl, steps, warmup):
-        sc, cols, bufs, g = make(wl)
+        sc, cols, bufs, g, create_ms = make(wl)
         for _ in range(warmup):
             step(sc, cols, bufs, g)
         sc.status()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)]
         barrier()
         t0 = time.perf_counter()
         rays = 0
@@ -228,15 +279,31 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         sc.status()
-        kern_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        kern_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
+        gather_ms = sum(e[2].elapsed_time(e[3]) for e in evs) / steps
+        tt = torch.tensor([dt], dtype=torch.float64, device=gdev)
+        per_rank = None
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            mine = torch.tensor([kern_ms, gather_ms, float(diag["rays"]), dt * 1e3 / steps], dtype=torch.float64, device=gdev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = torch.stack(allr).cpu().tolist()
         sc.close()
-        return rays, float(tt.item()), kern_ms, sc
+        return dict(rays=rays, dt=float(tt.item()), kernel_ms=kern_ms, gather_ms=gather_ms, create_ms=create_ms, per_rank=per_rank)
 
-    rays, dt, kern_ms, sc = run(args.workload, args.steps, args.warmup)
+    res = run(args.workload, args.steps, args.warmup)
+    rays, dt, kern_ms = res["rays"], res["dt"], res["kernel_ms"]
     rays_per_frame = rays / args.steps
+    ranks_seen = None
+    if world > 1:
+        # proof that the process group saw `world` ranks, each on a device of its own
+        props = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "device_index": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+              "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": seen}
     out = None
     if rank == 0:
         cfg = WORKLOADS[args.workload]
@@ -249,13 +316,13 @@ def main():
             "config": {"workload": "%s: %s, %dx%d, %d spp, maxTraceDepth %d, jitter %d" % (
                            args.workload, SCENE_NAMES.get(args.workload, "scene_spheres (12 surfaces, linear scan)"),
                            cfg["width"], cfg["height"], cfg["samplesPerPixel"], cfg["maxTraceDepth"], cfg["jitter"]),
-                       "rays_per_frame": rays_per_frame, "partition": "interleaved columns, %d rank(s), RCCL gather to rank 0" % world},
+                       "rays_per_frame": rays_per_frame,
+                       "partition": "interleaved columns, %d rank(s), %s gather to rank 0" % (world, "gloo (one shared GPU: rehearsal)" if share_one_gpu else "RCCL"),
+                       "scene_create_ms": res["create_ms"]},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / VALU_PEAK_TFLOPS, "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "kernel": "rt::trace_kernel (+ memsets and rt::resolve_kernel, <1 % of the bracket)",
-                         "peak_note": "157.3 TFLOP/s is v_pk_fma_f32 (measured 147); reference-order f32 arithmetic without "
-                                      "contraction issues v_add/v_mul at ~2.3 and compares/selects/min/max/fma at ~4.1 cycles "
-                                      "per wave64 instruction per SIMD (profiles/r02_valu_ops.txt, DESIGN.md section 6)",
+                         "peak_note": PEAK_NOTE,
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "flops_per_ray": flops / max(1, diag["rays"]),
                          "rays_by_kind": {"lambertian": diag["lamb"], "metal": diag["metal"], "dielectric": diag["diel"],
                                           "primary": diag["rays"] - diag["lamb"] - diag["metal"] - diag["diel"]},
@@ -267,20 +334,29 @@ def main():
                                  if args.workload in BVH_COST else None),
                          "lane_fill": diag["rays"] / max(1, diag["iters"] * 64), "waves": diag["waves"],
                          "mean_wave_clk": diag["sum_wave_clk"] / max(1, diag["waves"]), "max_wave_clk": diag["max_wave_clk"]},
+            "gather_ms": res["gather_ms"],
         }
+        if world > 1:
+            pr = res["per_rank"]
+            out["ranks_seen"] = ranks_seen
+            out["per_rank"] = {"kernel_ms": [r[0] for r in pr], "kernel_ms_min": min(r[0] for r in pr), "kernel_ms_max": max(r[0] for r in pr),
+                               "gather_ms": [r[1] for r in pr], "rays_last_frame": [int(r[2]) for r in pr],
+                               "ms_per_step": [r[3] for r in pr]}
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}
-        for wl, st in (("c1", 20), ("c2", 20), ("c3", 5), ("c5", 3), ("c4s", 2)):
+        for wl, st in (("c1", 20), ("c2", 20), ("c3", 5), ("c3_1", 20), ("c5", 3), ("c4s", 2)):
             if wl == args.workload:
                 continue
-            r, t, k, _ = run(wl, st, 1)
-            extra[wl] = {"Mrays_per_s": r / t / 1e6, "ms_per_frame": t / st * 1e3, "kernel_ms": k, "rays_per_frame": r / st}
+            r = run(wl, st, 1)
+            extra[wl] = {"Mrays_per_s": r["rays"] / r["dt"] / 1e6, "ms_per_frame": r["dt"] / st * 1e3, "kernel_ms": r["kernel_ms"],
+                         "rays_per_frame": r["rays"] / st, "scene_create_ms": r["create_ms"]}
         # the same frames through rt_render (HOST buffers: staging + PCIe copies of rgba/depth/ids inside the call);
         # reported beside the device-resident figures, never as `value`
         hostbuf = {}
-        for wl, st in (("c1", 10), ("c2", 5)):
+        for wl, st in (("c1", 20), ("c2", 5)):
             cfg = dict(WORKLOADS[wl])
             s = Scene(device=local_rank, **cfg)
+            s.renderScene()
             s.renderScene()
             t0 = time.perf_counter()
             for _ in range(st):
@@ -296,7 +372,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

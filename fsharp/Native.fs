@@ -1,4 +1,4 @@
-// Native.fs — P/Invoke surface of librt_hip.so (include/rt_abi.h, RT_ABI_VERSION 6) for the reference's F# host.
+// Native.fs — P/Invoke surface of librt_hip.so (include/rt_abi.h, RT_ABI_VERSION 7) for the reference's F# host.
 //
 // Compile position: after Surface.fs / SceneDefinitions.fs and before SceneGpu.fs (see raytracer.gpu.fsproj).
 // Every struct below is BLITTABLE: only primitive fields and System.Numerics Vector3 / Vector4 / Matrix4x4 (which are
@@ -55,7 +55,7 @@ type RtParams =
     val mutable twoPass : int32
 
 [<Literal>]
-let RtAbiVersion = 6
+let RtAbiVersion = 7
 
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
 extern int rt_abi_version()
@@ -67,6 +67,11 @@ extern int rt_scene_create(RtSurface[] surfaces, int64 n, int32 device, nativein
 extern void rt_scene_destroy(nativeint scene)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
 extern int rt_scene_status(nativeint scene)
+// optional: pin the frame buffers for DMA (the host keeps a GCHandle on them for as long as they are registered)
+[<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
+extern int rt_host_register(nativeint ptr, uint64 bytes)
+[<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
+extern int rt_host_unregister(nativeint ptr)
 // frameBuffer : Vector4[,] and depthBuffer : float32[,] exactly as Scene.fs:28-29 declares them (Array2D.create width
 // height: element [px,py] at px*height + py, the layout the library writes); blittable element types are pinned.
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]

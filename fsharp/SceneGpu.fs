@@ -9,6 +9,7 @@ module Raytracer.SceneGpu
 
 open System
 open System.Numerics
+open System.Runtime.InteropServices
 open Raytracer.Camera
 open Raytracer.Surface
 open Raytracer.Geometry.Sphere
@@ -71,6 +72,14 @@ type SceneGpu (devices : int list) =
             check (rt_scene_create(flat, int64 flat.Length, dev, &h))
             h) |> Array.ofList
 
+    // The frame buffers live as long as this object: pin them once and let the library DMA into them (optional; an
+    // unpinned buffer goes through the runtime's pageable copy, ~0.3 ms more per 640x480 frame).
+    let pins =
+        [| (GCHandle.Alloc(frameBuffer, GCHandleType.Pinned), uint64 (width * height * 16))
+           (GCHandle.Alloc(depthBuffer, GCHandleType.Pinned), uint64 (width * height * 4))
+           (GCHandle.Alloc(objectIds, GCHandleType.Pinned), uint64 (width * height * 8)) |]
+    let registered = pins |> Array.map (fun (h, bytes) -> rt_host_register(h.AddrOfPinnedObject(), bytes) = 0)
+
     new () = new SceneGpu([0])
 
     member self.FrameBuffer = frameBuffer
@@ -95,4 +104,8 @@ type SceneGpu (devices : int list) =
             check (rt_render_multi(handles, handles.Length, &cam, &p, frameBuffer, depthBuffer, objectIds, &maxFrameBufferDepth, &rayCount))
 
     interface IDisposable with
-        member self.Dispose () = handles |> Array.iter rt_scene_destroy
+        member self.Dispose () =
+            pins |> Array.iteri (fun i (h, _) ->
+                if registered.[i] then rt_host_unregister(h.AddrOfPinnedObject()) |> ignore
+                h.Free())
+            handles |> Array.iter rt_scene_destroy

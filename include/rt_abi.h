@@ -36,7 +36,8 @@ extern "C" {
 #define RT_E_INVALID      -1   /* bad argument (null pointer, size, enum value)              */
 #define RT_E_NO_DEVICE    -2   /* no HIP device / device index out of range                  */
 #define RT_E_HIP          -3   /* a HIP runtime call failed (message has the HIP error)      */
-#define RT_E_OVERFLOW     -4   /* a wave's LDS record pool overflowed its proven bound (a bug) */
+#define RT_E_OVERFLOW     -4   /* a wave's record pool overflowed: the proven bound of a linear-scan scene (a bug), or the
+                                  heuristic capacity of a BVH scene — the frame is invalid; see rt_scene_status         */
 #define RT_E_UNSUPPORTED  -5   /* valid request this build does not implement                */
 #define RT_E_RANGE        -6   /* a radiance contribution was NaN, infinite or >= 2^31 in magnitude
                                   (the pixel sums are 32.32 fixed point); it was dropped, the image is invalid */
@@ -111,9 +112,11 @@ typedef struct rt_params {
     int32_t  bvh_ring;            /* tuning/testing: traversal-stack entries kept in LDS, 0 = by tree size, 8 or 16
                                      (selects the kernel variant a BVH scene runs; results do not depend on it)   */
     int32_t  bvh_min_active;      /* tuning/testing: lanes still walking below which a wave refills; 0 = 28, 1..64 */
-    int32_t  two_pass;            /* tuning/testing: 0 = frames of at most 2^21 pixel-samples are rendered in two passes
+    int32_t  two_pass;            /* tuning/testing: 0 = frames of at most 2^19 pixel-samples are rendered in two passes
                                      (primaries, then their subtrees shared among all waves), 1 = always one pass;
-                                     the image does not depend on it                                                 */
+                                     the image does not depend on it.  rt_render_device_noalloc renders such a frame in
+                                     one pass when the list of primary hit records (up to 4 x 64 B per pixel-sample)
+                                     exceeds half of what is left of its scratch (640x480x1 already does)             */
 } rt_params;
 
 /* Estimators.  BRANCHING is what Scene.rayTrace computes (Scene.fs:51-72): every hit spawns SampleCount children
@@ -166,8 +169,9 @@ int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* pa
  * library load until the process ends) instead of buffers the scene grows with hipMalloc; the call performs no
  * hipMalloc/hipFree.  Limits: at most RT_NOALLOC_MAX_PIXELS rendered pixels per call (ncols*height), else
  * RT_E_UNSUPPORTED; the number of persistent waves shrinks until their spill areas fit (slower for deep traces, same
- * image).  All calls on one GPU share that GPU's array: two calls that overlap in time on one GPU race — serialise
- * them (one stream, or events).                                                                                    */
+ * image); a small frame whose two-pass list does not fit is rendered in one pass (rt_params.two_pass).  All calls on
+ * one GPU share that GPU's array: two calls that overlap in time on one GPU race — serialise them (one stream, or
+ * events).                                                                                                          */
 #define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
 #define RT_NOALLOC_MAX_PIXELS    (1 << 20)
 int  rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_params* params,
@@ -192,8 +196,23 @@ int  rt_find_closest(rt_scene* scene, int64_t nrays, const float* origins, const
 
 /* After a render on `scene` has completed: 0, RT_E_OVERFLOW if any wave's ray pool overflowed or RT_E_RANGE if a
  * radiance contribution did not fit the fixed-point sums (results are then invalid).  rt_render and rt_render_multi
- * check this themselves (and render a BVH scene again with a larger spill area on RT_E_OVERFLOW).               */
+ * check this themselves and render an overflowed BVH frame again.
+ * Recovery for callers of rt_render_device / rt_render_device_noalloc: a BVH scene's pool capacity is a heuristic
+ * (rays finish out of order there, so the linear scan's proven bound of 64 records per level does not hold).  When
+ * this call reports RT_E_OVERFLOW for a BVH scene it has DOUBLED the handle's capacity: render the frame again on the
+ * same handle (repeat until 0; the capacity stays raised for the handle's lifetime).  For a linear-scan scene
+ * RT_E_OVERFLOW is a bug.  (Test-only: with RT_TEST_TINY_SPILL=1 in the environment a BVH handle starts with no
+ * spill capacity at all, so that this path runs: tests/test_gpu_overflow.py.)                                    */
 int  rt_scene_status(rt_scene* scene);
+
+/* Optional: pin caller memory (hipHostRegister) so that rt_render / rt_render_multi copy a frame straight into it by
+ * DMA instead of through the runtime's pageable path (the 640x480x1 frame: 8.6 MB per call).  For a host that keeps its
+ * buffers for the life of the scene — the reference's `frameBuffer` / `depthBuffer` (Scene.fs:28-29) pinned with a
+ * GCHandle.  NO counterpart in the reference.  The caller unregisters before the memory is freed or moved; the library
+ * never registers a pointer on its own (a stale registration of freed-and-reused memory would silently receive the
+ * frame in the wrong pages).  Unregistered buffers keep working as before.                                        */
+int  rt_host_register(void* ptr, uint64_t bytes);
+int  rt_host_unregister(void* ptr);
 
 void rt_scene_destroy(rt_scene* scene);
 
@@ -202,7 +221,7 @@ const char* rt_last_error(void);
 
 /* ABI version: bumped whenever a struct layout or signature changes.                         */
 int  rt_abi_version(void);
-#define RT_ABI_VERSION 6
+#define RT_ABI_VERSION 7
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ ESTIMATOR_BRANCHING, ESTIMATOR_SINGLE_PATH = 0, 1
 KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
-RT_ABI_VERSION = 6
+RT_ABI_VERSION = 7
 RT_STATS_WORDS = 20
 RT_NOALLOC_SCRATCH_BYTES = 64 << 20
 RT_NOALLOC_MAX_PIXELS = 1 << 20
@@ -100,6 +100,8 @@ ABI_SYMBOLS = (
     "rt_render_multi",
     "rt_find_closest",
     "rt_scene_status",
+    "rt_host_register",
+    "rt_host_unregister",
     "rt_scene_destroy",
     "rt_last_error",
     "rt_abi_version",
@@ -137,6 +139,10 @@ def load_hip_library():
     lib.rt_find_closest.restype = C.c_int
     lib.rt_scene_status.argtypes = [C.c_void_p]
     lib.rt_scene_status.restype = C.c_int
+    lib.rt_host_register.argtypes = [C.c_void_p, C.c_uint64]
+    lib.rt_host_register.restype = C.c_int
+    lib.rt_host_unregister.argtypes = [C.c_void_p]
+    lib.rt_host_unregister.restype = C.c_int
     lib.rt_scene_destroy.argtypes = [C.c_void_p]
     lib.rt_scene_destroy.restype = None
     lib.rt_last_error.argtypes = []

@@ -165,6 +165,9 @@ struct rt_scene {
     size_t tmp_bytes = 0;
     float* d_frame = nullptr;           // rt_render_multi: the gathered frame on the root scene's device
     size_t frame_bytes = 0;
+    uint64_t* h_pin = nullptr;          // 64 bytes of pinned host memory: ray count, max depth bits, status word of a frame
+                                        // (truly asynchronous copies: rt_render fetches them with the frame, one wait)
+    bool peer_ok[kMaxDevices] = { false };   // rt_render_multi: this scene's device may store to device d (checked and enabled once)
 };
 
 namespace {
@@ -245,8 +248,19 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
     constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE + (SINGLE ? 16 : 0);
     int& cached_smem = sc->occ_smem[variant];
     int& cached_per_cu = sc->occ_per_cu[variant];
+    {   // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the KERNEL (per device), not to a scene: two scenes that
+        // run this instantiation with different pool sizes would otherwise lower each other's limit between a cached
+        // query and a launch.  It only ever grows: one maximum per instantiation and device, under a mutex.
+        static std::mutex attr_mutex;
+        static int attr_max[kMaxDevices] = { 0 };
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (sc->device < 0 || sc->device >= kMaxDevices) return fail(RT_E_UNSUPPORTED, "device %d beyond the %d this library tracks", sc->device, kMaxDevices);
+        if (attr_max[sc->device] < (int)smem) {
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_max[sc->device] = (int)smem;
+        }
+    }
     if (cached_smem != (int)smem) {
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int q = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 64, smem));
         // The query over-states what is resident: LDS is handed out in granules of 1 280 bytes (measured with
@@ -392,6 +406,13 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     // (2x the bound, never seen exceeded); rt_render doubles spill_factor and renders again on RT_E_OVERFLOW.
     // (+1: the second pass of a small frame puts up to 32 list records on top of a pool that still holds up to 16)
     c.max_spill = (sc->use_bvh ? 2 * sc->spill_factor * levels : levels) + 1;
+    // TEST KNOB (tests/test_gpu_overflow.py; include/rt_abi.h RT_E_OVERFLOW): with RT_TEST_TINY_SPILL set in the environment
+    // a BVH scene's waves get spill_factor - 1 blocks (0, 1, 3, 7, ... as the factor doubles), so that the first frame
+    // on a handle overflows and the recovery paths below (status_code, rt_render, rt_render_multi) actually run.
+    if (sc->use_bvh) {
+        const char* tiny = getenv("RT_TEST_TINY_SPILL");
+        if (tiny && tiny[0] == '1') c.max_spill = sc->spill_factor - 1;
+    }
 
     // Camera constants (Scene.fs:100-102, Camera.fs:27,32)
     const float* M = cam->cam_to_world;
@@ -477,23 +498,33 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     return RT_OK;
 }
 
-// Status word of the scene's last launch, read on its own stream (0 = OK).
-int status_after(rt_scene* sc, hipStream_t stream, int* raw)
+// What a frame's status word means.  A BVH scene's pool capacity is a heuristic (render_on_stream): when it was
+// exceeded the handle's capacity is doubled HERE, whoever asked — rt_render and rt_render_multi then render the frame
+// again, and a caller of rt_render_device / rt_render_device_noalloc that finds RT_E_OVERFLOW in rt_scene_status has
+// room on its next render of the same handle (those callers could not raise the capacity themselves).
+constexpr int kMaxSpillFactor = 1 << 10;
+int status_code(rt_scene* sc, int st)
 {
-    int st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, sc->d_status, sizeof st, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (raw) *raw = st;
-    if (st & kStatusOverflow) return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its bound; results are invalid");
+    if (st & kStatusOverflow) {
+        if (sc->use_bvh && sc->spill_factor < kMaxSpillFactor) {
+            sc->spill_factor *= 2;
+            return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its capacity; this frame is invalid, the handle's capacity is now %dx: render again",
+                        sc->spill_factor);
+        }
+        return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its bound; results are invalid");
+    }
     if (st & kStatusRange) return fail(RT_E_RANGE, "a radiance contribution was not finite or reached 2^31; it was dropped and the image is invalid");
     return RT_OK;
 }
+constexpr int kOverflowRetries = 4;       // rt_render / rt_render_multi render an overflowed BVH frame again this often
 
-// Compact staging of one scene's columns inside its d_tmp: stats | ids (8 B each) | rgba (16 B each) | depth (4 B each)
+// Compact staging of one scene's columns inside its d_tmp: stats | rgba (16 B each) | ids (8 B each) | depth (4 B each):
+// every block starts on a multiple of its own element size whatever npix is (rgba is read and written as float4)
 struct Staging { uint64_t* stats; uint64_t* ids; float* rgba; float* depth; };
+static_assert((RT_STATS_WORDS * 8) % 16 == 0, "rgba block of the staging must be 16-byte aligned");
 int staging_of(rt_scene* sc, size_t npix, Staging* s)
 {
-    const size_t off_ids = RT_STATS_WORDS * 8, off_rgba = off_ids + npix * 8, off_depth = off_rgba + npix * 16;
+    const size_t off_rgba = RT_STATS_WORDS * 8, off_ids = off_rgba + npix * 16, off_depth = off_ids + npix * 8;
     const int rc = ensure_tmp(sc, off_depth + npix * 4);
     if (rc) return rc;
     char* base = reinterpret_cast<char*>(sc->d_tmp);
@@ -502,19 +533,12 @@ int staging_of(rt_scene* sc, size_t npix, Staging* s)
     return RT_OK;
 }
 
-// Renders into the scene's staging on its own stream and waits; on a pool overflow of a BVH scene (heuristic capacity)
-// the spill area is doubled and the frame rendered again.
-int render_staged(rt_scene* sc, const rt_camera* cam, const rt_params* p, size_t npix, bool want_ids, Staging* st)
+// Queues the copies of a frame's scalars (ray count, max depth bits, status word) into the scene's pinned block.
+int fetch_scalars(rt_scene* sc, const Staging& st)
 {
-    int rc = staging_of(sc, npix, st);
-    if (rc) return rc;
-    for (int attempt = 0;; attempt++) {
-        rc = render_on_stream(sc, cam, p, sc->stream, st->rgba, st->depth, want_ids ? st->ids : nullptr, st->stats, false);
-        if (rc) return rc;
-        rc = status_after(sc, sc->stream, nullptr);
-        if (rc != RT_E_OVERFLOW || !sc->use_bvh || attempt >= 3) return rc;
-        sc->spill_factor *= 2;
-    }
+    HIP_TRY(hipMemcpyAsync(sc->h_pin, st.stats, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipMemcpyAsync(sc->h_pin + 2, sc->d_status, sizeof(int), hipMemcpyDeviceToHost, sc->stream));
+    return RT_OK;
 }
 
 }  // namespace
@@ -653,6 +677,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     hipError_t e = hipSetDevice(device);
     const size_t ng = geom.size();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&sc->h_pin), 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_geom), sizeof(GeomRec) * (ng > 0 ? ng : 1));
     if (e == hipSuccess && ng > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * ng, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_shade), sizeof(ShadeRec) * (n > 0 ? (size_t)n : 1));
@@ -700,6 +725,7 @@ void rt_scene_destroy(rt_scene* sc)
     if (sc->d_list) (void)hipFree(sc->d_list);
     if (sc->d_tmp) (void)hipFree(sc->d_tmp);
     if (sc->d_frame) (void)hipFree(sc->d_frame);
+    if (sc->h_pin) (void)hipHostFree(sc->h_pin);
     delete sc;
 }
 
@@ -721,8 +747,30 @@ int rt_scene_status(rt_scene* sc)
     HIP_TRY(hipSetDevice(sc->device));
     int st = 0;
     HIP_TRY(hipMemcpy(&st, sc->d_status, sizeof st, hipMemcpyDeviceToHost));
-    if (st & kStatusOverflow) return fail(RT_E_OVERFLOW, "a wave's ray pool overflowed its bound; results are invalid");
-    if (st & kStatusRange) return fail(RT_E_RANGE, "a radiance contribution was not finite or reached 2^31; it was dropped and the image is invalid");
+    // (a frame's status word is cleared by the next render, so an overflow is seen, and the capacity doubled, once:
+    // a second query without a render in between doubles it again, which is harmless)
+    return status_code(sc, st);
+}
+
+// Pins caller memory for DMA (hipHostRegister): rt_render / rt_render_multi then copy a frame straight into it instead
+// of through the runtime's pageable path (measured on the 640x480x1 frame).  Explicit on purpose:
+// a library that registered whatever pointer it is handed would keep mappings of memory the caller has since freed
+// and reallocated — a silent wrong-frame hazard.
+int rt_host_register(void* ptr, uint64_t bytes)
+{
+    if (!ptr || bytes == 0) return fail(RT_E_INVALID, "null or empty host range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_E_NO_DEVICE, "no HIP device (this library has no CPU path)");
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(RT_E_HIP, "hipHostRegister(%p, %llu): %s", ptr, (unsigned long long)bytes, hipGetErrorString(e)); }
+    return RT_OK;
+}
+
+int rt_host_unregister(void* ptr)
+{
+    if (!ptr) return fail(RT_E_INVALID, "null host pointer");
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(RT_E_HIP, "hipHostUnregister(%p): %s", ptr, hipGetErrorString(e)); }
     return RT_OK;
 }
 
@@ -737,17 +785,27 @@ int rt_render(rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgb
     const size_t npix = (size_t)columns_of(p) * (size_t)p->height;
     if (npix == 0) { if (max_depth) *max_depth = 0.0f; if (ray_count) *ray_count = 0; return RT_OK; }
     Staging st;
-    rc = render_staged(sc, cam, p, npix, object_id != nullptr, &st);
+    rc = staging_of(sc, npix, &st);
     if (rc) return rc;
-    // the scene's own stream: other scenes on this device keep running (no device-wide synchronisation)
-    uint64_t stats[2];
-    HIP_TRY(hipMemcpyAsync(rgba, st.rgba, npix * 16, hipMemcpyDeviceToHost, sc->stream));
-    HIP_TRY(hipMemcpyAsync(depth, st.depth, npix * 4, hipMemcpyDeviceToHost, sc->stream));
-    if (object_id) HIP_TRY(hipMemcpyAsync(object_id, st.ids, npix * 8, hipMemcpyDeviceToHost, sc->stream));
-    HIP_TRY(hipMemcpyAsync(stats, st.stats, sizeof stats, hipMemcpyDeviceToHost, sc->stream));
-    HIP_TRY(hipStreamSynchronize(sc->stream));
-    if (ray_count) *ray_count = stats[0];
-    if (max_depth) { uint32_t bits = (uint32_t)stats[1]; memcpy(max_depth, &bits, 4); }
+    // The frame, its scalars and its status word are all queued behind the kernels on the scene's own stream and waited
+    // for ONCE (other scenes on this device keep running: no device-wide synchronisation).  The status is looked at
+    // afterwards: a frame that has to be rendered again (a BVH scene whose heuristic pool capacity was exceeded: doubled
+    // by status_code) is simply copied again.  No object-ID traffic at all when the caller passes no buffer for them.
+    for (int attempt = 0;; attempt++) {
+        rc = render_on_stream(sc, cam, p, sc->stream, st.rgba, st.depth, object_id ? st.ids : nullptr, st.stats, false);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(rgba, st.rgba, npix * 16, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipMemcpyAsync(depth, st.depth, npix * 4, hipMemcpyDeviceToHost, sc->stream));
+        if (object_id) HIP_TRY(hipMemcpyAsync(object_id, st.ids, npix * 8, hipMemcpyDeviceToHost, sc->stream));
+        rc = fetch_scalars(sc, st);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        rc = status_code(sc, (int)(uint32_t)sc->h_pin[2]);
+        if (rc != RT_E_OVERFLOW || !sc->use_bvh || attempt >= kOverflowRetries) break;
+    }
+    if (rc) return rc;
+    if (ray_count) *ray_count = sc->h_pin[0];
+    if (max_depth) { uint32_t bits = (uint32_t)sc->h_pin[1]; memcpy(max_depth, &bits, 4); }
     g_err[0] = 0;
     return RT_OK;
 }
@@ -781,58 +839,77 @@ int rt_render_multi(rt_scene* const* scenes, int32_t nscenes, const rt_camera* c
     std::vector<Staging> st((size_t)nscenes);
     std::vector<int> ncols((size_t)nscenes, 0);
     uint64_t rays = 0; float maxd = 0.0f;
-    for (int attempt = 0;; attempt++) {
+    // Every way out of the frame loop below goes through `drain`: work already queued on the scenes' streams writes into
+    // root->d_frame and into the scenes' staging, which a follow-up call may free or regrow.
+    auto drain = [&](int upto) {
+        for (int i = 0; i <= upto && i < nscenes; i++) {
+            if (hipSetDevice(scenes[i]->device) == hipSuccess) (void)hipStreamSynchronize(scenes[i]->stream);
+        }
+    };
     // 1. every scene starts its share (asynchronous: the devices render concurrently) and queues its placement
-    for (int i = 0; i < nscenes; i++) {
+    auto start_share = [&](int i) -> int {
         rt_scene* sc = scenes[i];
         rt_params pi = *p;
         pi.x_begin = i; pi.x_step = nscenes;
         ncols[(size_t)i] = share_columns(W, i, nscenes);
-        if (ncols[(size_t)i] <= 0) continue;
+        if (ncols[(size_t)i] <= 0) return RT_OK;
         HIP_TRY(hipSetDevice(sc->device));
-        if (sc->device != root->device) {
+        if (sc->device != root->device && !sc->peer_ok[root->device]) {
+            // once per pair of handles' devices: the query and the enable cost host time on every frame otherwise
             int can = 0;
             HIP_TRY(hipDeviceCanAccessPeer(&can, sc->device, root->device));
             if (!can) return fail(RT_E_UNSUPPORTED, "device %d cannot store to device %d (no peer access)", sc->device, root->device);
             const hipError_t pe = hipDeviceEnablePeerAccess(root->device, 0);
             if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(RT_E_HIP, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(pe));
             (void)hipGetLastError();
+            sc->peer_ok[root->device] = true;
         }
         const size_t npix = (size_t)ncols[(size_t)i] * (size_t)H;
-        rc = staging_of(sc, npix, &st[(size_t)i]);
-        if (rc) return rc;
-        rc = render_on_stream(sc, cam, &pi, sc->stream, st[(size_t)i].rgba, st[(size_t)i].depth, object_id ? st[(size_t)i].ids : nullptr,
-                              st[(size_t)i].stats, false);
-        if (rc) return rc;
-        const long long quads = (long long)npix;
-        hipLaunchKernelGGL(place_columns_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, sc->stream,
+        int r = staging_of(sc, npix, &st[(size_t)i]);
+        if (r) return r;
+        r = render_on_stream(sc, cam, &pi, sc->stream, st[(size_t)i].rgba, st[(size_t)i].depth, object_id ? st[(size_t)i].ids : nullptr,
+                             st[(size_t)i].stats, false);
+        if (r) return r;
+        hipLaunchKernelGGL(place_columns_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, sc->stream,
                            st[(size_t)i].rgba, st[(size_t)i].depth,
                            object_id ? reinterpret_cast<const unsigned long long*>(st[(size_t)i].ids) : nullptr,
                            f_rgba, f_depth, object_id ? reinterpret_cast<unsigned long long*>(f_ids) : nullptr,
                            ncols[(size_t)i], H, i, nscenes);
         HIP_TRY(hipGetLastError());
-    }
-    // 2. wait for every share, reduce the scalars (maxFrameBufferDepth: max, Scene.fs:47-48; ray count: sum)
-    rays = 0; maxd = 0.0f;
-    int first_err = RT_OK;
-    for (int i = 0; i < nscenes; i++) {
-        if (ncols[(size_t)i] <= 0) continue;
+        return fetch_scalars(sc, st[(size_t)i]);
+    };
+    // 2. wait for a share, take its scalars (maxFrameBufferDepth: max, Scene.fs:47-48; ray count: sum)
+    auto finish_share = [&](int i, int* status) -> int {
         rt_scene* sc = scenes[i];
         HIP_TRY(hipSetDevice(sc->device));
-        uint64_t stats[2];
-        HIP_TRY(hipMemcpyAsync(stats, st[(size_t)i].stats, sizeof stats, hipMemcpyDeviceToHost, sc->stream));
-        rc = status_after(sc, sc->stream, nullptr);
-        if (rc && !first_err) first_err = rc;
-        rays += stats[0];
-        uint32_t bits = (uint32_t)stats[1]; float m; memcpy(&m, &bits, 4);
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        *status = status_code(sc, (int)(uint32_t)sc->h_pin[2]);     // (doubles the capacity of a BVH handle that overflowed)
+        rays += sc->h_pin[0];
+        uint32_t bits = (uint32_t)sc->h_pin[1]; float m; memcpy(&m, &bits, 4);
         maxd = std::max(maxd, m);
-    }
-    if (!first_err) break;
-    // a BVH scene's pool capacity is a heuristic (render_on_stream): double it on every handle and render the frame again
-    bool any_bvh = false;
-    for (int i = 0; i < nscenes; i++) any_bvh = any_bvh || scenes[i]->use_bvh;
-    if (first_err != RT_E_OVERFLOW || !any_bvh || attempt >= 3) return first_err;
-    for (int i = 0; i < nscenes; i++) scenes[i]->spill_factor *= 2;
+        return RT_OK;
+    };
+    for (int attempt = 0;; attempt++) {
+        for (int i = 0; i < nscenes; i++) {
+            rc = start_share(i);
+            if (rc) { char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep); drain(i); memcpy(g_err, keep, sizeof keep); return rc; }
+        }
+        rays = 0; maxd = 0.0f;
+        int first_err = RT_OK;
+        char first_msg[sizeof g_err] = "";
+        for (int i = 0; i < nscenes; i++) {
+            if (ncols[(size_t)i] <= 0) continue;
+            int status = RT_OK;
+            rc = finish_share(i, &status);
+            if (rc) { char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep); drain(nscenes - 1); memcpy(g_err, keep, sizeof keep); return rc; }
+            if (status && !first_err) { first_err = status; memcpy(first_msg, g_err, sizeof first_msg); }
+        }
+        if (!first_err) break;
+        // every share has been waited for.  A BVH scene's pool capacity is a heuristic: the handles that overflowed have
+        // had theirs doubled (status_code); render the frame again
+        bool any_bvh = false;
+        for (int i = 0; i < nscenes; i++) any_bvh = any_bvh || scenes[i]->use_bvh;
+        if (first_err != RT_E_OVERFLOW || !any_bvh || attempt >= kOverflowRetries) { memcpy(g_err, first_msg, sizeof first_msg); return first_err; }
     }
     // 3. one copy of the gathered frame to the host
     HIP_TRY(hipSetDevice(root->device));

@@ -1,0 +1,109 @@
+"""RT_E_OVERFLOW: detection (trace_kernel: a push that finds neither room in LDS nor a free spill block) and recovery.
+A BVH scene's pool capacity is a heuristic — rays finish out of order there, so the in-order bound of the linear scan
+(64 records per level, DESIGN.md "Pool bound") does not hold — and with the default capacity no frame has ever exceeded
+it, so none of this code ran before.  The test-only environment switch RT_TEST_TINY_SPILL=1 (include/rt_abi.h,
+rt_scene_status) starts a BVH handle with NO spill capacity: the first frame overflows, and
+
+* rt_render_device + rt_scene_status report -4, the status call doubles the handle's capacity, and rendering again on
+  the same handle converges to the right frame (device-buffer callers had no way to recover);
+* rt_render and rt_render_multi render the frame again by themselves and return the oracle's frame."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_amd import abi, host, scenes
+from raytracer_amd.scene import Scene
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed():
+    base = np.frombuffer(bytes(host.flatten_surfaces(host.SceneDefinitions.scene_spheres)), dtype=abi.surface_dtype, count=12).copy()
+    return np.concatenate([base, scenes.heightfield_mesh(12, environment=False, base=-5.9, amplitude=1.0)])
+
+
+# one pass (two_pass=1 means off): a wave then holds up to 64 records per level, far beyond the 128 its LDS ring keeps
+KW = dict(width=96, height=72, samplesPerPixel=2, maxTraceDepth=6, jitter=1, seed=5, two_pass=1)
+
+
+def _device_frame(s):
+    import torch
+    dev = torch.device("cuda", 0)
+    rgba = torch.zeros((s.width, s.height, 4), dtype=torch.float32, device=dev)
+    depth = torch.zeros((s.width, s.height), dtype=torch.float32, device=dev)
+    ids = torch.zeros((s.width, s.height), dtype=torch.int64, device=dev)
+    stats = torch.zeros(abi.RT_STATS_WORDS, dtype=torch.int64, device=dev)
+    s.renderColumnsDevice(rgba.data_ptr(), depth.data_ptr(), ids.data_ptr(), stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return rgba.cpu().numpy(), depth.cpu().numpy(), ids.cpu().numpy().astype(np.uint64), int(stats[0].item())
+
+
+def test_device_render_reports_overflow_and_the_status_call_makes_room(monkeypatch):
+    good = Scene(surfaces=_mixed(), **KW)
+    good.renderScene()
+    monkeypatch.setenv("RT_TEST_TINY_SPILL", "1")
+    s = Scene(surfaces=_mixed(), **KW)
+    codes = []
+    for _ in range(8):
+        frame = _device_frame(s)
+        try:
+            s.status()
+            codes.append(0)
+            break
+        except abi.RtError as e:
+            codes.append(e.code)
+            assert "render again" in str(e)
+    assert codes[0] == abi.RT_E_OVERFLOW, codes          # no spill block at all: the first frame must overflow
+    assert codes[-1] == 0 and set(codes[:-1]) == {abi.RT_E_OVERFLOW}, codes
+    assert np.array_equal(frame[0], good.frameBuffer) and np.array_equal(frame[1], good.depthBuffer)
+    assert np.array_equal(frame[2], good.objectIds) and frame[3] == good.rayCount
+    # the capacity stays raised: the next frame on this handle is clean at once
+    _device_frame(s)
+    s.status()
+
+
+def test_rt_render_retries_and_returns_the_oracle_frame(monkeypatch):
+    monkeypatch.setenv("RT_TEST_TINY_SPILL", "1")
+    _compare(Scene(surfaces=_mixed(), **KW))             # renderScene -> rt_render, against the brute-force oracle
+
+
+def test_rt_render_multi_retries_and_returns_the_oracle_frame(monkeypatch):
+    monkeypatch.setenv("RT_TEST_TINY_SPILL", "1")
+    s = Scene(surfaces=_mixed(), **KW)
+    others = [Scene(surfaces=_mixed(), **KW) for _ in range(2)]
+    s.renderSceneMulti(others)
+    ref = O.render(s.surfaces, s.camera, s.params())
+    assert np.array_equal(s.objectIds, ref["ids"]) and s.rayCount == ref["rays"] and s.maxFrameBufferDepth == ref["max_depth"]
+    assert np.array_equal(s.depthBuffer, ref["depth"]) and np.max(np.abs(s.frameBuffer - ref["rgba"])) <= 1e-4
+
+
+def test_noalloc_entry_reports_overflow_too(monkeypatch):
+    import torch
+    good = Scene(surfaces=_mixed(), **KW)
+    good.renderScene()
+    monkeypatch.setenv("RT_TEST_TINY_SPILL", "1")
+    s = Scene(surfaces=_mixed(), **KW)
+    dev = torch.device("cuda", 0)
+    rgba = torch.zeros((s.width, s.height, 4), dtype=torch.float32, device=dev)
+    depth = torch.zeros((s.width, s.height), dtype=torch.float32, device=dev)
+    codes = []
+    for _ in range(8):
+        s.renderColumnsDeviceNoAlloc(rgba.data_ptr(), depth.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        try:
+            s.status()
+            codes.append(0)
+            break
+        except abi.RtError as e:
+            codes.append(e.code)
+    assert codes[0] == abi.RT_E_OVERFLOW and codes[-1] == 0, codes
+    assert np.array_equal(rgba.cpu().numpy(), good.frameBuffer)
+
+
+def test_linear_scan_scenes_ignore_the_switch(monkeypatch):
+    """The knob only touches the heuristic capacity of BVH scenes; a linear-scan scene keeps its proven bound."""
+    monkeypatch.setenv("RT_TEST_TINY_SPILL", "1")
+    s = Scene(width=96, height=72, samplesPerPixel=2, maxTraceDepth=6, jitter=1, seed=5)
+    _device_frame(s)
+    s.status()

@@ -48,6 +48,13 @@ def test_c2_stochastic_16spp_depth4():
     _compare(Scene(width=200, height=160, samplesPerPixel=16, maxTraceDepth=4, jitter=1, seed=1))
 
 
+def test_c2_full_size_800x640_16spp_depth4():
+    """configs[1] at its full size: 274 M rays; the oracle on the box's host cores needs a few seconds."""
+    import os
+    _compare(Scene(width=800, height=640, samplesPerPixel=16, maxTraceDepth=4, jitter=1, seed=1),
+             nthreads=min(16, os.cpu_count() or 1))
+
+
 @pytest.mark.parametrize("spp", [1, 2, 3, 5, 64, 100])
 def test_sample_counts(spp):
     _compare(Scene(width=40, height=30, samplesPerPixel=spp, maxTraceDepth=3, jitter=1, seed=7))
