@@ -67,19 +67,20 @@ extern int rt_scene_create(RtSurface[] surfaces, int64 n, int32 device, nativein
 extern void rt_scene_destroy(nativeint scene)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
 extern int rt_scene_status(nativeint scene)
-// optional: pin the frame buffers for DMA (the host keeps a GCHandle on them for as long as they are registered)
+// optional: pinned host memory for the frame buffers (PinnedArray2D below)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
-extern int rt_host_register(nativeint ptr, uint64 bytes)
+extern int rt_host_alloc(uint64 bytes, nativeint& out)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
-extern int rt_host_unregister(nativeint ptr)
-// frameBuffer : Vector4[,] and depthBuffer : float32[,] exactly as Scene.fs:28-29 declares them (Array2D.create width
-// height: element [px,py] at px*height + py, the layout the library writes); blittable element types are pinned.
+extern void rt_host_free(nativeint ptr)
+// rgba / depth / objectId: width*height elements laid out like `Array2D.create width height` (Scene.fs:28-29: element
+// [px,py] at px*height + py).  Pass PinnedArray2D.Pointer (below), or the address of a GCHandle-pinned managed
+// Vector4[,] / float32[,] (GCHandle.Alloc(a, GCHandleType.Pinned).AddrOfPinnedObject()) — the layout is the same.
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
-extern int rt_render(nativeint scene, RtCamera& cam, RtParams& p, Vector4[,] rgba, float32[,] depth,
-                     uint64[,] objectId, float32& maxDepth, uint64& rayCount)
+extern int rt_render(nativeint scene, RtCamera& cam, RtParams& p, nativeint rgba, nativeint depth,
+                     nativeint objectId, float32& maxDepth, uint64& rayCount)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
-extern int rt_render_multi(nativeint[] scenes, int32 nscenes, RtCamera& cam, RtParams& p, Vector4[,] rgba,
-                           float32[,] depth, uint64[,] objectId, float32& maxDepth, uint64& rayCount)
+extern int rt_render_multi(nativeint[] scenes, int32 nscenes, RtCamera& cam, RtParams& p, nativeint rgba,
+                           nativeint depth, nativeint objectId, float32& maxDepth, uint64& rayCount)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
 extern int rt_render_device(nativeint scene, RtCamera& cam, RtParams& p, nativeint stream, nativeint dRgba,
                             nativeint dDepth, nativeint dObjectId, nativeint dStats)
@@ -92,3 +93,27 @@ extern int rt_find_closest(nativeint scene, int64 nrays, Vector3[] origins, Vect
 /// failwith on a negative return code, with the library's message (the style of Camera.fs:45)
 let check (rc : int) =
     if rc <> 0 then failwith (sprintf "rt_hip error %d: %s" rc (Marshal.PtrToStringAnsi(rt_last_error())))
+
+/// A width x height array of a blittable element type in pinned host memory of the library (rt_host_alloc), indexed
+/// like the reference's `Array2D.create width height` buffers: `a.[px, py]` is element px*height + py, so
+/// `frameBuffer.[px,py]` in saveFrameBuffer / saveDepthBuffer (Scene.fs:128,139) compiles unchanged against it.
+/// The library copies a frame into such a block by DMA; a managed array goes through a staged pageable copy.
+type PinnedArray2D<'T when 'T : unmanaged> (width : int, height : int, init : 'T) =
+    let bytes = uint64 width * uint64 height * uint64 sizeof<'T>
+    let mutable ptr = 0n
+    do
+        check (rt_host_alloc(bytes, &ptr))
+        let p = NativeInterop.NativePtr.ofNativeInt<'T> ptr
+        for i in 0 .. width * height - 1 do NativeInterop.NativePtr.set p i init
+    member self.Pointer = ptr
+    member self.Length1 = width
+    member self.Length2 = height
+    member self.Item
+        with get (px : int, py : int) : 'T =
+            if px < 0 || px >= width || py < 0 || py >= height then raise (IndexOutOfRangeException())
+            NativeInterop.NativePtr.get (NativeInterop.NativePtr.ofNativeInt<'T> ptr) (px * height + py)
+        and set (px : int, py : int) (v : 'T) =
+            if px < 0 || px >= width || py < 0 || py >= height then raise (IndexOutOfRangeException())
+            NativeInterop.NativePtr.set (NativeInterop.NativePtr.ofNativeInt<'T> ptr) (px * height + py) v
+    interface IDisposable with
+        member self.Dispose () = if ptr <> 0n then (rt_host_free ptr; ptr <- 0n)

@@ -9,7 +9,6 @@ module Raytracer.SceneGpu
 
 open System
 open System.Numerics
-open System.Runtime.InteropServices
 open Raytracer.Camera
 open Raytracer.Surface
 open Raytracer.Geometry.Sphere
@@ -50,9 +49,10 @@ type SceneGpu (devices : int list) =
     let samplesPerPixel = 1
     let maxTraceDepth = 5us
     let backgroundColor = Vector3.Zero
-    let frameBuffer = Array2D.create width height Vector4.Zero
-    let depthBuffer = Array2D.create width height System.Single.MaxValue
-    let objectIds = Array2D.create width height 0UL
+    // Scene.fs:28-29 `Array2D.create width height ...`, in pinned memory of the library: same `.[px,py]` indexing
+    let frameBuffer = new PinnedArray2D<Vector4>(width, height, Vector4.Zero)
+    let depthBuffer = new PinnedArray2D<float32>(width, height, System.Single.MaxValue)
+    let objectIds = new PinnedArray2D<uint64>(width, height, 0UL)
     let mutable maxFrameBufferDepth = 0.0f
     let mutable rayCount = 0UL
     let surfaces : (Surface array) = scene_spheres |> Array.ofList
@@ -71,14 +71,6 @@ type SceneGpu (devices : int list) =
             let mutable h = 0n
             check (rt_scene_create(flat, int64 flat.Length, dev, &h))
             h) |> Array.ofList
-
-    // The frame buffers live as long as this object: pin them once and let the library DMA into them (optional; an
-    // unpinned buffer goes through the runtime's pageable copy, ~0.3 ms more per 640x480 frame).
-    let pins =
-        [| (GCHandle.Alloc(frameBuffer, GCHandleType.Pinned), uint64 (width * height * 16))
-           (GCHandle.Alloc(depthBuffer, GCHandleType.Pinned), uint64 (width * height * 4))
-           (GCHandle.Alloc(objectIds, GCHandleType.Pinned), uint64 (width * height * 8)) |]
-    let registered = pins |> Array.map (fun (h, bytes) -> rt_host_register(h.AddrOfPinnedObject(), bytes) = 0)
 
     new () = new SceneGpu([0])
 
@@ -99,13 +91,13 @@ type SceneGpu (devices : int list) =
         p.jitter <- 1; p.seed <- 1UL
         p.xBegin <- 0; p.xEnd <- width; p.xStep <- 1
         if handles.Length = 1 then
-            check (rt_render(handles.[0], &cam, &p, frameBuffer, depthBuffer, objectIds, &maxFrameBufferDepth, &rayCount))
+            check (rt_render(handles.[0], &cam, &p, frameBuffer.Pointer, depthBuffer.Pointer, objectIds.Pointer, &maxFrameBufferDepth, &rayCount))
         else
-            check (rt_render_multi(handles, handles.Length, &cam, &p, frameBuffer, depthBuffer, objectIds, &maxFrameBufferDepth, &rayCount))
+            check (rt_render_multi(handles, handles.Length, &cam, &p, frameBuffer.Pointer, depthBuffer.Pointer, objectIds.Pointer, &maxFrameBufferDepth, &rayCount))
 
     interface IDisposable with
         member self.Dispose () =
-            pins |> Array.iteri (fun i (h, _) ->
-                if registered.[i] then rt_host_unregister(h.AddrOfPinnedObject()) |> ignore
-                h.Free())
             handles |> Array.iter rt_scene_destroy
+            (frameBuffer :> IDisposable).Dispose ()
+            (depthBuffer :> IDisposable).Dispose ()
+            (objectIds :> IDisposable).Dispose ()

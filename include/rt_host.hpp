@@ -15,6 +15,7 @@
 // -ffp-contract=off (tests/test_host_cpp.py checks the flattened scene bit for bit against the Python mirror).
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -291,6 +292,56 @@ public:
         const std::string err = rc == RT_OK ? "" : rt_last_error();
         rt_scene_destroy(sc);
         if (rc != RT_OK) throw std::runtime_error(err);
+    }
+
+    // ---- Scene.fs:123-144: the image stage.  ImageSharp's JPEG encoder is replaced by binary PPM (P6); everything up
+    // to the encoder is the reference's: image.Item(px,py) <- Rgba32(frameBuffer.[px,py]) and, for the depth image,
+    // Rgba32(Vector4(Vector3(depth / maxFrameBufferDepth), 1)).
+    // ImageSharp `Rgba32(Vector4)` packs a channel as v*255 + 0.5, clamped to [0,255], truncated to a byte.
+    static uint8_t packChannel(float v)
+    {
+        float s = v * 255.0f + 0.5f;
+        if (s != s) s = 0.0f;
+        s = s < 0.0f ? 0.0f : (s > 255.0f ? 255.0f : s);
+        return (uint8_t)s;
+    }
+    // [height][width][4] bytes, row py / column px: what saveFrameBuffer hands to the encoder (Scene.fs:125-130)
+    std::vector<uint8_t> frameBufferImage() const
+    {
+        std::vector<uint8_t> img((size_t)width * height * 4);
+        for (int px = 0; px < width; px++)
+            for (int py = 0; py < height; py++)
+                for (int c = 0; c < 4; c++)
+                    img[((size_t)py * width + px) * 4 + c] = packChannel(frameBuffer[((size_t)px * height + py) * 4 + c]);
+        return img;
+    }
+    // Scene.fs:136-142: depth / maxFrameBufferDepth in the three colour channels, alpha 1; a miss holds Single.MaxValue
+    // (Scene.fs:29) and saturates to white
+    std::vector<uint8_t> depthBufferImage() const
+    {
+        std::vector<uint8_t> img((size_t)width * height * 4);
+        for (int px = 0; px < width; px++)
+            for (int py = 0; py < height; py++) {
+                const uint8_t g = packChannel(depthBuffer[(size_t)px * height + py] / maxFrameBufferDepth);
+                uint8_t* o = &img[((size_t)py * width + px) * 4];
+                o[0] = g; o[1] = g; o[2] = g; o[3] = packChannel(1.0f);
+            }
+        return img;
+    }
+    void saveFrameBuffer(const std::string& path = "sphere.ppm") const { writePpm(path, frameBufferImage()); }     // Scene.fs:123-132
+    void saveDepthBuffer(const std::string& path = "depth.ppm") const { writePpm(path, depthBufferImage()); }      // Scene.fs:134-144
+
+private:
+    void writePpm(const std::string& path, const std::vector<uint8_t>& rgba) const
+    {
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write " + path);
+        std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+        std::vector<uint8_t> rgb((size_t)width * height * 3);
+        for (size_t i = 0; i < (size_t)width * height; i++) { rgb[3 * i] = rgba[4 * i]; rgb[3 * i + 1] = rgba[4 * i + 1]; rgb[3 * i + 2] = rgba[4 * i + 2]; }
+        const bool ok = std::fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
+        std::fclose(f);
+        if (!ok) throw std::runtime_error("short write to " + path);
     }
 };
 

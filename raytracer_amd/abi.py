@@ -100,8 +100,8 @@ ABI_SYMBOLS = (
     "rt_render_multi",
     "rt_find_closest",
     "rt_scene_status",
-    "rt_host_register",
-    "rt_host_unregister",
+    "rt_host_alloc",
+    "rt_host_free",
     "rt_scene_destroy",
     "rt_last_error",
     "rt_abi_version",
@@ -139,10 +139,10 @@ def load_hip_library():
     lib.rt_find_closest.restype = C.c_int
     lib.rt_scene_status.argtypes = [C.c_void_p]
     lib.rt_scene_status.restype = C.c_int
-    lib.rt_host_register.argtypes = [C.c_void_p, C.c_uint64]
-    lib.rt_host_register.restype = C.c_int
-    lib.rt_host_unregister.argtypes = [C.c_void_p]
-    lib.rt_host_unregister.restype = C.c_int
+    lib.rt_host_alloc.argtypes = [C.c_uint64, P(C.c_void_p)]
+    lib.rt_host_alloc.restype = C.c_int
+    lib.rt_host_free.argtypes = [C.c_void_p]
+    lib.rt_host_free.restype = None
     lib.rt_scene_destroy.argtypes = [C.c_void_p]
     lib.rt_scene_destroy.restype = None
     lib.rt_last_error.argtypes = []
@@ -153,6 +153,28 @@ def load_hip_library():
         raise RuntimeError("librt_hip.so ABI version mismatch: rebuild")
     _lib = lib
     return lib
+
+
+class PinnedBlock:
+    """`nbytes` of pinned host memory from rt_host_alloc, exposed to numpy (`np.asarray(block)` is a u8 view whose base
+    keeps this object, and with it the memory, alive; the memory is returned when the last view is gone)."""
+
+    def __init__(self, lib, nbytes):
+        ptr = C.c_void_p()
+        check(lib, lib.rt_host_alloc(nbytes, C.byref(ptr)))
+        self._lib, self.ptr, self.nbytes = lib, ptr.value, nbytes
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def array(self, dtype, shape):
+        return np.asarray(self).view(dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.rt_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
 
 
 class RtError(RuntimeError):

@@ -133,6 +133,8 @@ struct rt_scene {
     int device = 0;
     int64_t n = 0;
     hipStream_t stream = nullptr;              // rt_render / rt_find_closest / rt_render_multi work of this scene
+    hipStream_t copy_stream = nullptr;         // rt_render: depth and object IDs leave for the host while the frame still renders
+    hipEvent_t ev_primaries = nullptr;         // recorded behind the launch that writes depth and object IDs
     GeomRec* d_geom = nullptr;
     ShadeRec* d_shade = nullptr;
     // One control block, cleared by one memset per frame (a fill is a launch: a 640x480x1 frame of 0.7 ms paid for six):
@@ -338,8 +340,11 @@ constexpr unsigned long long kTwoPassMaxSamples = 1ull << 19;
 int columns_of(const rt_params* p) { return (p->x_end - p->x_begin + p->x_step - 1) / p->x_step; }
 
 // The render behind rt_render_device and rt_render_device_noalloc: memsets, trace_kernel, resolve_kernel on `stream`.
+// `after_primaries` (optional) is recorded behind the launch that writes depth and object IDs: the first pass of a small
+// frame, else the only one.
 int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hipStream_t stream,
-                     float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats, bool noalloc)
+                     float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats, bool noalloc,
+                     hipEvent_t after_primaries = nullptr)
 {
     if (!sc) return fail(RT_E_INVALID, "scene is null");
     int rc = check_params(cam, p);
@@ -483,6 +488,7 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     if (two_pass) {
         rc = launch(std::integral_constant<int, 1>());
         if (rc) return rc;
+        if (after_primaries) { HIP_TRY(hipEventRecord(after_primaries, stream)); after_primaries = nullptr; }
         c.counter = sc->d_counter2;
         rc = launch(std::integral_constant<int, 2>());
     } else if (c.total < (unsigned long long)kSampleMajorBelow * 16ull * (unsigned long long)sc->num_cus) {
@@ -491,6 +497,7 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
         rc = launch(std::integral_constant<int, 3>());
     } else rc = launch(std::integral_constant<int, 0>());
     if (rc) return rc;
+    if (after_primaries) HIP_TRY(hipEventRecord(after_primaries, stream));
     const unsigned pixel_blocks = (unsigned)((npix + 255) / 256);
     hipLaunchKernelGGL(resolve_kernel, dim3(pixel_blocks + (d_stats ? (unsigned)((kStatsWords + 3) / 4) : 0u)), dim3(256), 0, stream, accum, d_rgba,
                        npix, p->spp, pixel_blocks, sc->d_statpart, reinterpret_cast<unsigned long long*>(d_stats));
@@ -677,6 +684,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     hipError_t e = hipSetDevice(device);
     const size_t ng = geom.size();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sc->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_primaries, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&sc->h_pin), 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_geom), sizeof(GeomRec) * (ng > 0 ? ng : 1));
     if (e == hipSuccess && ng > 0) e = hipMemcpy(sc->d_geom, geom.data(), sizeof(GeomRec) * ng, hipMemcpyHostToDevice);
@@ -714,7 +723,9 @@ void rt_scene_destroy(rt_scene* sc)
 {
     if (!sc) return;
     (void)hipSetDevice(sc->device);
+    if (sc->copy_stream) { (void)hipStreamSynchronize(sc->copy_stream); (void)hipStreamDestroy(sc->copy_stream); }
     if (sc->stream) { (void)hipStreamSynchronize(sc->stream); (void)hipStreamDestroy(sc->stream); }
+    if (sc->ev_primaries) (void)hipEventDestroy(sc->ev_primaries);
     if (sc->d_geom) (void)hipFree(sc->d_geom);
     if (sc->d_shade) (void)hipFree(sc->d_shade);
     if (sc->d_ctl) (void)hipFree(sc->d_ctl);
@@ -752,26 +763,25 @@ int rt_scene_status(rt_scene* sc)
     return status_code(sc, st);
 }
 
-// Pins caller memory for DMA (hipHostRegister): rt_render / rt_render_multi then copy a frame straight into it instead
-// of through the runtime's pageable path (measured on the 640x480x1 frame).  Explicit on purpose:
-// a library that registered whatever pointer it is handed would keep mappings of memory the caller has since freed
-// and reallocated — a silent wrong-frame hazard.
-int rt_host_register(void* ptr, uint64_t bytes)
+// Pinned host memory for the caller's frame buffers (hipHostMalloc): rt_render / rt_render_multi copy a frame into it
+// by DMA (measured on the 640x480x1 frame: 0.13 ms for rgba + depth) instead of through the runtime's pageable path
+// (0.45 ms).  Pinning memory the caller already owns (hipHostRegister) is refused by this pool's driver ("invalid
+// argument" for every flag and alignment), so the library hands the memory out instead.
+int rt_host_alloc(uint64_t bytes, void** out)
 {
-    if (!ptr || bytes == 0) return fail(RT_E_INVALID, "null or empty host range");
+    if (!out) return fail(RT_E_INVALID, "out is null");
+    *out = nullptr;
+    if (bytes == 0) return fail(RT_E_INVALID, "empty host block");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RT_E_NO_DEVICE, "no HIP device (this library has no CPU path)");
-    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(RT_E_HIP, "hipHostRegister(%p, %llu): %s", ptr, (unsigned long long)bytes, hipGetErrorString(e)); }
+    const hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(RT_E_HIP, "hipHostMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e)); }
     return RT_OK;
 }
 
-int rt_host_unregister(void* ptr)
+void rt_host_free(void* ptr)
 {
-    if (!ptr) return fail(RT_E_INVALID, "null host pointer");
-    const hipError_t e = hipHostUnregister(ptr);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(RT_E_HIP, "hipHostUnregister(%p): %s", ptr, hipGetErrorString(e)); }
-    return RT_OK;
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 int rt_render(rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgba, float* depth, uint64_t* object_id,
@@ -791,15 +801,19 @@ int rt_render(rt_scene* sc, const rt_camera* cam, const rt_params* p, float* rgb
     // for ONCE (other scenes on this device keep running: no device-wide synchronisation).  The status is looked at
     // afterwards: a frame that has to be rendered again (a BVH scene whose heuristic pool capacity was exceeded: doubled
     // by status_code) is simply copied again.  No object-ID traffic at all when the caller passes no buffer for them.
+    // Depth and object IDs are final once the primaries are traced (Scene.fs:80: first sample's primary hit): they
+    // leave on a second stream while the rest of the frame renders (the second pass of a small frame is 7/8 of it).
     for (int attempt = 0;; attempt++) {
-        rc = render_on_stream(sc, cam, p, sc->stream, st.rgba, st.depth, object_id ? st.ids : nullptr, st.stats, false);
-        if (rc) return rc;
+        rc = render_on_stream(sc, cam, p, sc->stream, st.rgba, st.depth, object_id ? st.ids : nullptr, st.stats, false, sc->ev_primaries);
+        if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }
+        HIP_TRY(hipStreamWaitEvent(sc->copy_stream, sc->ev_primaries, 0));
+        HIP_TRY(hipMemcpyAsync(depth, st.depth, npix * 4, hipMemcpyDeviceToHost, sc->copy_stream));
+        if (object_id) HIP_TRY(hipMemcpyAsync(object_id, st.ids, npix * 8, hipMemcpyDeviceToHost, sc->copy_stream));
         HIP_TRY(hipMemcpyAsync(rgba, st.rgba, npix * 16, hipMemcpyDeviceToHost, sc->stream));
-        HIP_TRY(hipMemcpyAsync(depth, st.depth, npix * 4, hipMemcpyDeviceToHost, sc->stream));
-        if (object_id) HIP_TRY(hipMemcpyAsync(object_id, st.ids, npix * 8, hipMemcpyDeviceToHost, sc->stream));
         rc = fetch_scalars(sc, st);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->copy_stream));
         rc = status_code(sc, (int)(uint32_t)sc->h_pin[2]);
         if (rc != RT_E_OVERFLOW || !sc->use_bvh || attempt >= kOverflowRetries) break;
     }

@@ -38,7 +38,6 @@ class Scene:
         self.rayCount = 0
         self._lib = None
         self._scene = C.c_void_p()
-        self._pinned = []       # host arrays registered for DMA (kept alive here until close() unregisters them)
 
     # -- plumbing ---------------------------------------------------------------------------
     def params(self, x_begin=0, x_end=None, x_step=1):
@@ -54,18 +53,20 @@ class Scene:
         self._lib = abi.load_hip_library()
         arr = host.flatten_surfaces(self.surfaces)
         abi.check(self._lib, self._lib.rt_scene_create(arr, len(self.surfaces), self.device, C.byref(self._scene)))
-        # the frame buffers belong to this object for its lifetime: pin them so rt_render copies by DMA (optional —
-        # a failed registration only means the pageable copy path)
-        for a in (self.frameBuffer, self.depthBuffer, self.objectIds):
-            if self._lib.rt_host_register(a.ctypes.data, a.nbytes) == abi.RT_OK:
-                self._pinned.append(a)
+        # the frame buffers move to pinned host memory (rt_host_alloc), so that rt_render copies into them by DMA; the
+        # arrays keep their block alive for as long as anyone holds them (abi.PinnedBlock)
+        try:
+            for name in ("frameBuffer", "depthBuffer", "objectIds"):
+                old = getattr(self, name)
+                new = abi.PinnedBlock(self._lib, old.nbytes).array(old.dtype, old.shape)
+                new[...] = old
+                setattr(self, name, new)
+        except abi.RtError:
+            pass                  # pageable buffers work too, only slower
         return self._scene
 
     def close(self):
         if self._scene:
-            for a in self._pinned:
-                self._lib.rt_host_unregister(a.ctypes.data)
-            self._pinned = []
             self._lib.rt_scene_destroy(self._scene)
             self._scene = C.c_void_p()
 

@@ -58,9 +58,18 @@ def test_device_render_reports_overflow_and_the_status_call_makes_room(monkeypat
     assert codes[-1] == 0 and set(codes[:-1]) == {abi.RT_E_OVERFLOW}, codes
     assert np.array_equal(frame[0], good.frameBuffer) and np.array_equal(frame[1], good.depthBuffer)
     assert np.array_equal(frame[2], good.objectIds) and frame[3] == good.rayCount
-    # the capacity stays raised: the next frame on this handle is clean at once
-    _device_frame(s)
-    s.status()
+    # Which wave holds how many records depends on the hand-out (run to run), so with the switch's marginal capacities
+    # (0, 1, 3, 7 ... blocks) a later frame may overflow once more; every report doubles the capacity, so it converges.
+    for _ in range(8):
+        again = _device_frame(s)
+        try:
+            s.status()
+            break
+        except abi.RtError as e:
+            assert e.code == abi.RT_E_OVERFLOW
+    else:
+        raise AssertionError("the capacity did not converge")
+    assert np.array_equal(again[0], good.frameBuffer) and again[3] == good.rayCount
 
 
 def test_rt_render_retries_and_returns_the_oracle_frame(monkeypatch):

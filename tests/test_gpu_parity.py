@@ -225,8 +225,8 @@ def test_c4s_4k_64spp_sphere_scene_frame_properties():
 
 
 def test_rccl_collectives_of_the_frame_gather():
-    """The collectives FrameGatherer issues for N > 1 (gather of the packed f32 block, f64 all-reduces), run on RCCL
-    with a one-rank group: the multi-GPU bench itself only runs on the driver's 8-GPU node."""
+    """The collectives FrameGatherer issues for N > 1 (one gather per output into views of a [world, mc, H, ...] tensor,
+    one f64 all-gather of the scalars), run on RCCL with a one-rank group; two real ranks: test_gpu_bench_launch.py."""
     import torch
     import torch.distributed as dist
     from raytracer_amd import multi
@@ -242,18 +242,21 @@ def test_rccl_collectives_of_the_frame_gather():
     try:
         s = Scene(width=64, height=48, samplesPerPixel=1, maxTraceDepth=3, jitter=0)
         s.renderScene()
-        g = multi.FrameGatherer(s.width, s.height, dev, rank=0, world=1)
-        rgba = torch.from_numpy(s.frameBuffer).to(dev)
-        depth = torch.from_numpy(s.depthBuffer).to(dev)
-        g.part[:, :, 0:4] = rgba
-        g.part[:, :, 4] = depth
-        dist.gather(g.part, g.recv, dst=0)
-        st = torch.tensor([float(s.rayCount)], dtype=torch.float64, device=dev)
-        dist.all_reduce(st, op=dist.ReduceOp.SUM)
-        mx = torch.tensor([float(s.maxFrameBufferDepth)], dtype=torch.float64, device=dev)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        g = multi.FrameGatherer(s.width, s.height, dev, rank=0, world=1, with_ids=True)
+        rgba, depth, ids = g.render_targets()
+        rgba.copy_(torch.from_numpy(s.frameBuffer))
+        depth.copy_(torch.from_numpy(s.depthBuffer))
+        ids.copy_(torch.from_numpy(s.objectIds.astype(np.int64)))
+        recv = torch.zeros((1,) + tuple(g.part_rgba.shape), dtype=torch.float32, device=dev)
+        dist.gather(g.part_rgba, list(recv.unbind(0)), dst=0)
+        both = torch.zeros((1, 2), dtype=torch.float64, device=dev)
+        dist.all_gather(list(both.unbind(0)), torch.tensor([float(s.rayCount), float(s.maxFrameBufferDepth)], dtype=torch.float64, device=dev))
         torch.cuda.synchronize()
-        assert torch.equal(g.recv[0][:, :, 0:4], rgba) and int(st.item()) == s.rayCount
-        assert float(mx.item()) == float(np.float32(s.maxFrameBufferDepth))
+        assert torch.equal(recv[0], rgba) and int(both[0, 0].item()) == s.rayCount
+        assert float(both[0, 1].item()) == float(np.float32(s.maxFrameBufferDepth))
+        total, maxd = g.gather(rgba, depth, ids, s.rayCount, s.maxFrameBufferDepth)
+        assert total == s.rayCount and np.float32(maxd) == np.float32(s.maxFrameBufferDepth)
+        assert np.array_equal(g.rgba.cpu().numpy(), s.frameBuffer) and np.array_equal(g.depth.cpu().numpy(), s.depthBuffer)
+        assert np.array_equal(g.ids.cpu().numpy().astype(np.uint64), s.objectIds)
     finally:
         dist.destroy_process_group()

@@ -35,6 +35,42 @@ def test_cpp_scene_definitions_and_camera_flatten_like_the_python_mirror():
     assert out == expect
 
 
+def _read_ppm(path):
+    raw = open(path, "rb").read()
+    magic, dims, maxval, data = raw.split(b"\n", 3)
+    w, h = (int(x) for x in dims.split())
+    assert magic == b"P6" and maxval == b"255" and len(data) == w * h * 3
+    return np.frombuffer(data, dtype=np.uint8).reshape(h, w, 3)
+
+
+def test_cpp_save_frame_and_depth_buffer_pack_like_the_python_image_stage(tmp_path):
+    """saveFrameBuffer / saveDepthBuffer of include/rt_host.hpp (Scene.fs:123-144: Rgba32(Vector4) pack, depth / max,
+    white = miss) against Scene.frameBufferImage() / depthBufferImage(), byte for byte, on buffers that hold every
+    special case: values below 0 and above 1, exact .5 boundaries, NaN, infinities, Single.MaxValue depths."""
+    from raytracer_amd.scene import Scene
+    w, h = 37, 23
+    rng = np.random.default_rng(5)
+    s = Scene(width=w, height=h)
+    fb = rng.uniform(-0.2, 1.2, (w, h, 4)).astype(np.float32)
+    fb[0, 0] = (np.nan, np.inf, -np.inf, 1.0)
+    fb[1, :, 0] = (np.arange(h, dtype=np.float32) + np.float32(0.5)) / np.float32(255.0)     # pack boundaries
+    fb[2, :, 1] = np.arange(h, dtype=np.float32) / np.float32(255.0)
+    db = rng.uniform(0.5, 40.0, (w, h)).astype(np.float32)
+    db[rng.uniform(size=(w, h)) < 0.2] = np.finfo(np.float32).max                       # misses (Scene.fs:29)
+    s.frameBuffer, s.depthBuffer = fb, db
+    s.maxFrameBufferDepth = float(db[db < 1e30].max())
+    src = tmp_path / "in.bin"
+    with open(src, "wb") as f:
+        f.write(np.array([w, h], dtype=np.int32).tobytes())
+        f.write(np.array([s.maxFrameBufferDepth], dtype=np.float32).tobytes())
+        f.write(fb.tobytes())
+        f.write(db.tobytes())
+    frame, depth = tmp_path / "frame.ppm", tmp_path / "depth.ppm"
+    subprocess.run([_build("save_images"), str(src), str(frame), str(depth)], check=True, timeout=60)
+    assert np.array_equal(_read_ppm(frame), s.frameBufferImage()[:, :, :3])
+    assert np.array_equal(_read_ppm(depth), s.depthBufferImage()[:, :, :3])
+
+
 @pytest.mark.gpu
 def test_cpp_render_scene_matches_python_scene(tmp_path):
     from raytracer_amd.scene import Scene
