@@ -89,7 +89,9 @@ surface_dtype = np.dtype(
 assert surface_dtype.itemsize == C.sizeof(rt_surface), (surface_dtype.itemsize, C.sizeof(rt_surface))
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_HIP_PATH = os.path.join(_PKG_DIR, "csrc", "librt_hip.so")
+# RT_HIP_LIBRARY selects another build of the same library (tools/ab_libs.sh: same-box A/B of kernel variants built with
+# `make -C raytracer_amd/csrc variant TAG=... DEFS=...`); it is still this HIP library or nothing.
+LIB_HIP_PATH = os.environ.get("RT_HIP_LIBRARY") or os.path.join(_PKG_DIR, "csrc", "librt_hip.so")
 
 # every symbol include/rt_abi.h declares
 ABI_SYMBOLS = (

@@ -33,6 +33,24 @@ constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a lea
 // and 1M-sphere scenes; re-tuned in round 2, when the rounds had become cheaper: 16/16 -> 16/8 is +3 % on the mixed scene)
 constexpr int kBvhInnerMin = 16, kBvhLeafMin = 8;
 constexpr int kBvhStack = 64;             // host guarantees 3 * (tree depth) + 1 <= kBvhStack
+// EXPERIMENT (profiles/r03_node_bytes.txt): log2 of the bytes from one node to the next.  7 = the 128-byte node itself;
+// 8 = the same nodes 256 bytes apart (twice the node footprint in the caches at exactly the same instruction stream),
+// which measures how much of a frame's time depends on the bytes a node occupies — the question behind quantised
+// 64-byte nodes.
+#ifndef RT_BVH_NODE_SHIFT
+#define RT_BVH_NODE_SHIFT 7
+#endif
+constexpr int kBvhNodeShift = RT_BVH_NODE_SHIFT;
+static_assert(kBvhNodeShift >= 7 && kBvhNodeShift <= 9, "a node is 128 bytes");
+// EXPERIMENT, second half: RT_BVH_NODE_SPLIT (needs a node shift of 8) puts rows 4..6 of a node into the NEXT 128-byte
+// line, so that every node visit touches two cache lines instead of one — twice the working set in lines, same
+// instruction stream: the mirror image of a 64-byte node, which would halve it.
+#ifndef RT_BVH_NODE_SPLIT
+#define RT_BVH_NODE_SPLIT 0
+#endif
+static_assert(!RT_BVH_NODE_SPLIT || RT_BVH_NODE_SHIFT >= 8, "a split node needs 256 bytes");
+// byte offset of row r (lo.x lo.y lo.z hi.x hi.y hi.z ref) inside a node
+constexpr uint32_t node_row(int r) { return (RT_BVH_NODE_SPLIT && r >= 4) ? 64u + 16u * (uint32_t)r : 16u * (uint32_t)r; }
 
 // (t, idx) is a better hit than (tmin, best): closer, or equally close with a lower array index
 RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
@@ -149,8 +167,8 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     const f3 noi_lo = F3(noi.x - 1e-6f * fabsf(noi.x), noi.y - 1e-6f * fabsf(noi.y), noi.z - 1e-6f * fabsf(noi.z));
     const f3 noi_hi = F3(noi.x + 1e-6f * fabsf(noi.x), noi.y + 1e-6f * fabsf(noi.y), noi.z + 1e-6f * fabsf(noi.z));
     // byte offsets, inside a node, of the planes met first / last on each axis (lo.x lo.y lo.z hi.x hi.y hi.z)
-    const uint32_t onx = (inv.x < 0.0f) ? 48u : 0u, ony = (inv.y < 0.0f) ? 64u : 16u, onz = (inv.z < 0.0f) ? 80u : 32u;
-    const uint32_t ofx = 48u - onx, ofy = 80u - ony, ofz = 112u - onz;
+    const uint32_t onx = (inv.x < 0.0f) ? node_row(3) : node_row(0), ony = (inv.y < 0.0f) ? node_row(4) : node_row(1), onz = (inv.z < 0.0f) ? node_row(5) : node_row(2);
+    const uint32_t ofx = (node_row(0) + node_row(3)) - onx, ofy = (node_row(1) + node_row(4)) - ony, ofz = (node_row(2) + node_row(5)) - onz;
     const char* const node_bytes = reinterpret_cast<const char*>(bvh.nodes);
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kBvhDone;
@@ -191,14 +209,14 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     auto issue = [&]() {
         if (do_in | do_leaf) {
             uint32_t o0, o1;        // inner: the node; leaf: first and second record
-            if (do_in) { o0 = cur << 7; o1 = o0; }             // 128 bytes per node; the allocation is < 4 GB (host check)
+            if (do_in) { o0 = cur << kBvhNodeShift; o1 = o0; }             // 128 bytes per node; the allocation is < 4 GB (host check)
             else {
                 const uint32_t first = (cur & 0x7fffffffu) >> 3;
                 o0 = bvh.pdata_off + first * 48u;              // 48-byte records
                 o1 = o0 + (((cur & 6u) != 0u) ? 48u : 0u);
             }
             const uint32_t a0 = o0 + (do_in ? onx : 0u), a1 = o0 + (do_in ? ofx : 16u), a2 = o0 + (do_in ? ony : 32u);
-            const uint32_t a3 = o1 + (do_in ? ofy : 0u), a4 = o1 + (do_in ? onz : 16u), a5 = o1 + (do_in ? ofz : 32u), a6 = o1 + (do_in ? 96u : 32u);
+            const uint32_t a3 = o1 + (do_in ? ofy : 0u), a4 = o1 + (do_in ? onz : 16u), a5 = o1 + (do_in ? ofz : 32u), a6 = o1 + (do_in ? node_row(6) : 32u);
             d[0] = *reinterpret_cast<const float4*>(node_bytes + a0); d[1] = *reinterpret_cast<const float4*>(node_bytes + a1);
             d[2] = *reinterpret_cast<const float4*>(node_bytes + a2); d[3] = *reinterpret_cast<const float4*>(node_bytes + a3);
             d[4] = *reinterpret_cast<const float4*>(node_bytes + a4); d[5] = *reinterpret_cast<const float4*>(node_bytes + a5);

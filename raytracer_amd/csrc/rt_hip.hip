@@ -381,13 +381,15 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     c.status = sc->d_status;
     c.total = (unsigned long long)npix * (unsigned long long)p->spp;
     c.npix = (unsigned int)npix;
-    {   // multiplier of the hand-out permutation: near npix/phi, coprime with npix
-        unsigned long long m = (unsigned long long)((double)npix * 0.6180339887498949) | 1ull;
+    // multiplier of the hand-out permutation of n pixels: near n/phi, coprime with n
+    auto multiplier = [](unsigned long long n) -> unsigned int {
+        if (n <= 1) return 0u;
+        unsigned long long m = (unsigned long long)((double)n * 0.6180339887498949) | 1ull;
         auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long t = x % y; x = y; y = t; } return x; };
-        while (gcd(m, (unsigned long long)npix) != 1) m += 2;
-        c.scatter = (unsigned int)(m % (unsigned long long)npix);
-        if (npix == 1) c.scatter = 0;
-    }
+        while (gcd(m, n) != 1) m += 2;
+        return (unsigned int)(m % n);
+    };
+    c.scatter = multiplier((unsigned long long)npix);
     a.nsurf = (int)sc->nloose; c.H = p->height; a.spp = p->spp; a.max_depth = p->max_trace_depth;
     c.jitter = p->jitter ? 1 : 0;
     a.bg_nonzero = (p->background[0] != 0.0f || p->background[1] != 0.0f || p->background[2] != 0.0f) ? 1 : 0;
@@ -494,6 +496,11 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     } else if (c.total < (unsigned long long)kSampleMajorBelow * 16ull * (unsigned long long)sc->num_cus) {
         // a wave's share of the frame is small enough for one heavy refill to matter: sample-major hand-out (4K frames
         // keep the samples of a pixel together: they meet in the pixel cache, and their tail is under 1 % of the frame)
+        // ... in one strip of columns per XCD (trace_kernel, take()): the permutation works inside a strip
+        c.part_pixels = (unsigned int)((npix + kXcdParts - 1) / kXcdParts);
+        c.part_items = c.part_pixels * (unsigned int)p->spp;
+        c.scatter = multiplier(c.part_pixels);
+        c.scatter_tail = multiplier((unsigned long long)npix % c.part_pixels);      // (0 when the strips are all full)
         rc = launch(std::integral_constant<int, 3>());
     } else rc = launch(std::integral_constant<int, 0>());
     if (rc) return rc;
@@ -675,7 +682,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
         bvh_build(bprims, src_pdata, hb);
         if (3 * hb.depth + 1 > kBvhStack) { delete sc; return fail(RT_E_UNSUPPORTED, "BVH depth %d exceeds the traversal stack", hb.depth); }
         // the traversal addresses nodes and records by 32-bit byte offsets and leaf references hold 28-bit record indices
-        if ((hb.nodes.size() + hb.pdata.size()) * sizeof(float4) >= (1ull << 32) || bprims.size() >= (1ull << 28)) {
+        if ((hb.nodes.size() * ((size_t)1 << (kBvhNodeShift - 7)) + hb.pdata.size()) * sizeof(float4) >= (1ull << 32) || bprims.size() >= (1ull << 28)) {
             delete sc; return fail(RT_E_UNSUPPORTED, "BVH of %zu primitives is too large", bprims.size());
         }
         sc->nnodes = (int)(hb.nodes.size() / 8); sc->bvh_depth = hb.depth; sc->nprims = (int64_t)bprims.size();
@@ -692,6 +699,13 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_shade), sizeof(ShadeRec) * (n > 0 ? (size_t)n : 1));
     if (e == hipSuccess && n > 0) e = hipMemcpy(sc->d_shade, h_shade.data(), sizeof(ShadeRec) * (size_t)n, hipMemcpyHostToDevice);
     if (use_bvh && !hb.nodes.empty()) {
+        if (kBvhNodeShift > 7) {     // experiment build: the same nodes, further apart (rt_bvh.h RT_BVH_NODE_SHIFT)
+            const size_t stride = (size_t)1 << (kBvhNodeShift - 4), nn = hb.nodes.size() / 8;
+            std::vector<float4> spread(nn * stride, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            for (size_t i = 0; i < nn; i++)
+                for (int r = 0; r < 7; r++) spread[i * stride + node_row(r) / 16] = hb.nodes[i * 8 + r];
+            hb.nodes.swap(spread);
+        }
         const size_t nbytes = sizeof(float4) * hb.nodes.size(), pbytes = sizeof(float4) * hb.pdata.size();
         sc->pdata_off = (uint32_t)nbytes;
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), nbytes + pbytes);

@@ -66,6 +66,12 @@ struct ColdArgs {
     int group_shift;                // PHASE 3 (one-pass frame handed out sample-major): hand-out position q =
                                     // ((sample / G) * npix + pixel position) * G + sample % G with G = 1 << group_shift (a divisor
                                     // of spp) instead of pixel position * spp + sample (see the primary ray in trace_kernel)
+    // PHASE 3 again: the frame is cut into kXcdParts strips of part_pixels consecutive compact pixel positions (whole
+    // columns side by side), each with its own hand-out counter and the order above INSIDE the strip; a wave starts
+    // on the strip of the XCD it runs on (see take() in trace_kernel)
+    unsigned int part_pixels;       // pixels of a strip (the last non-empty strip may hold fewer)
+    unsigned int part_items;        // = part_pixels * spp: hand-out positions of a strip
+    unsigned int scatter_tail;      // the hand-out multiplier of the last, shorter strip (`scatter` is the full strips')
 };
 
 // Hot constants: live in SGPRs for the whole kernel.
@@ -92,6 +98,10 @@ RT_DEV ColdPtr cold_args()
 // bits of the status word a launch leaves behind (rt_scene_status)
 constexpr uint32_t kNoPixel = 0xffffffffu;   // (frames have fewer than 2^31 pixels)
 constexpr int kPixelCacheMinSpp = 8;         // samples per pixel from which finished samples go through the pixel cache
+#ifndef RT_KIND_SORT
+#define RT_KIND_SORT 0
+#endif
+constexpr bool kKindSort = RT_KIND_SORT != 0;   // group an iteration's pushes by surface kind (trace_kernel, "order of this iteration's pushes")
 constexpr int kStatusOverflow = 1;      // a wave's record pool overflowed
 constexpr int kStatusRange = 2;         // a radiance contribution was NaN, infinite or >= 2^31 and was dropped
 
@@ -102,6 +112,11 @@ constexpr int kCounterStride = 16;      // in u64
 constexpr int kListChunk = 32;          // list entries a wave takes at a time in the second pass of a small frame ...
 constexpr int kListLow = 16;            // ... when its pool holds at most this many records (measured on 640x480x1: chunks of
                                         // 8 / 16 entries 2.0 / 1.2 ms, thresholds 0 / 48 records 0.83 / 1.09 ms against 0.83 ms)
+#ifndef RT_XCD_PARTS
+#define RT_XCD_PARTS 8
+#endif
+constexpr int kXcdParts = RT_XCD_PARTS; // strips of a sample-major one-pass frame = XCDs of the chip (each has its own L2); 1 = one strip (A/B builds)
+static_assert(kXcdParts <= kCounterParts, "one hand-out counter per strip");
 constexpr int kStatsParts = 128;
 constexpr int kStatsWords = 20;         // == RT_STATS_WORDS (include/rt_abi.h)
 
@@ -222,6 +237,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
     uint32_t n_lamb = 0, n_metal = 0, n_diel = 0;   // child rays intersected, by the kind that scattered them
     uint32_t n_refill = 0;                      // hand-outs this wave has taken (two-pass frames)
+#ifdef RT_KIND_STATS
+    uint32_t dbg_pure = 0, dbg_with_children = 0, dbg_with_diel = 0;
+#endif
 #ifdef RT_PHASE_TIMING
     unsigned long long ph_gen = 0, ph_scan = 0, ph_trav = 0, ph_shade = 0, ph_t = __builtin_readcyclecounter();
 #define RT_PHASE(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - ph_t; ph_t = now_; }
@@ -238,11 +256,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
 
     // Hand-out: `want` consecutive items of [0, total) from the wave's current part of the index space; when that
     // part is used up the wave moves to the next part that has items left.  Returns the number taken (0: none left).
-    constexpr int PARTS = (PHASE == 2) ? kCounterParts : 1;
-    int cur_part = (int)(blockIdx.x % PARTS);
-    auto take = [&](int want, unsigned long long total, unsigned long long& base_out) -> int {
+    // XCD-aware hand-out (PHASE 3).  Each XCD has its own 4 MB L2 and every XCD used to walk the whole scene: the 87 MB
+    // tree of the 1M-sphere frame ran at a 65 % L2 hit rate, and that frame's time follows the lines it misses (with a
+    // node spread over two cache lines instead of one it takes 68 % longer, the mesh frames 1.5 %: profiles/
+    // r03_node_bytes.txt).  So the frame is cut into one strip of columns per XCD and a wave starts on the strip of the
+    // XCD it runs on (HW_REG_XCC_ID; which blocks share an XCD is not promised by HIP, so it is read, not computed):
+    // the primaries and first bounces of one XCD's waves then stay in one part of the scene and of the tree.  A wave
+    // whose strip is used up moves to the next strip that has items left, so the balance stays dynamic.
+    // (pixel-major 4K frames keep one counter: strips measured +-0 on the 4K sphere scene, +0.5 % on the 4K mixed scene)
+    constexpr bool kStrips = PHASE == 3;
+    constexpr int PARTS = (PHASE == 2) ? kCounterParts : kStrips ? kXcdParts : 1;
+    int cur_part = kStrips ? (int)(xcc_id() % (uint32_t)PARTS) : (int)(blockIdx.x % PARTS);
+    auto take = [&](int want, unsigned long long total, unsigned long long per, unsigned long long& base_out) -> int {
         const ColdPtr ca = cold_args();
-        const unsigned long long per = (total + PARTS - 1) / PARTS;
         while (true) {
             const unsigned long long lo = (unsigned long long)cur_part * per;
             const unsigned long long hi = (lo + per < total) ? lo + per : total;
@@ -316,7 +342,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             const ColdPtr ca = cold_args();
             const int want = min(kListChunk, popc_mask(freemask));
             unsigned long long base = 0;
-            const int n = take(want, (unsigned long long)ca->list_cap, base);
+            const int n = take(want, (unsigned long long)ca->list_cap, ((unsigned long long)ca->list_cap + PARTS - 1) / PARTS, base);
             if (n == 0) exhausted = true;
             else {
                 const size_t cap = ca->list_cap;
@@ -388,7 +414,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                     limit = (base + per < limit) ? base + per : limit;
                     base += (unsigned long long)n_refill;
                 } else {
-                    const int n = take(want, limit, base);
+                    const int n = take(want, limit, kStrips ? (unsigned long long)ca->part_items : limit, base);
                     limit = base + (unsigned long long)n;       // (n == 0: nothing left)
                     if (n == 0) base = limit = 0;
                 }
@@ -441,16 +467,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 // Between the two, G samples of a pixel stay together (the BVH kernels: neighbouring primaries walk the
                 // tree together, which is worth more there than the last bit of balance).
                 constexpr bool smajor = PHASE == 3;
-                const int gs = smajor ? ca->group_shift : 0;
-                const unsigned long long qt = q >> gs;
-                const unsigned long long qdiv = smajor ? (unsigned long long)ca->npix : (unsigned long long)spp;
-                const unsigned long long qq = qt / qdiv, qr = qt - qq * qdiv;
-                const unsigned long long o64 = smajor ? qr : qq;
-                const int s = smajor ? (int)(qq << gs) + (int)(q & ((1ull << gs) - 1ull)) : (int)qr;
-                // Consecutive hand-outs go to pixels far apart in the image (a fixed bijection), so that every
-                // refill mixes cheap and expensive pixels: with row-major hand-out one wave would start on 64
-                // neighbouring floor pixels (thousands of rays each) and finish long after the others.
-                const uint32_t o = (uint32_t)((o64 * (unsigned long long)ca->scatter) % (unsigned long long)ca->npix);
+                int s; uint32_t o;
+                if (smajor) {
+                    // position j inside the strip this refill came from (cur_part: take() has just set it); a PHASE 3 frame
+                    // has fewer than 2^27 pixel-samples, so 32-bit arithmetic
+                    const int gs = ca->group_shift;
+                    const uint32_t first = (uint32_t)cur_part * ca->part_pixels;            // first compact pixel position of the strip
+                    const uint32_t np = min(ca->part_pixels, ca->npix - first);
+                    const uint32_t j = (uint32_t)(q - (unsigned long long)cur_part * (unsigned long long)ca->part_items);
+                    const uint32_t qt = j >> gs, sg = qt / np, l = qt - sg * np;
+                    s = (int)(sg << gs) + (int)(j & ((1u << gs) - 1u));
+                    const uint32_t m = (np == ca->part_pixels) ? ca->scatter : ca->scatter_tail;
+                    o = first + (uint32_t)(((unsigned long long)l * (unsigned long long)m) % (unsigned long long)np);
+                } else {
+                    const unsigned long long qq = q / (unsigned long long)spp;
+                    s = (int)(q - qq * (unsigned long long)spp);
+                    // Consecutive hand-outs go to pixels far apart in the image (a fixed bijection), so that every
+                    // refill mixes cheap and expensive pixels: with row-major hand-out one wave would start on 64
+                    // neighbouring floor pixels (thousands of rays each) and finish long after the others.
+                    o = (uint32_t)((qq * (unsigned long long)ca->scatter) % (unsigned long long)ca->npix);
+                }
                 const int k = (int)(o / (uint32_t)ca->H), py = (int)(o - (uint32_t)k * (uint32_t)ca->H);
                 const int px = ca->x_begin + k * ca->x_step;
                 const uint64_t pixel = (uint64_t)px * (uint64_t)ca->H + (uint64_t)py;
@@ -595,6 +631,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             }
         }
 
+#ifdef RT_KIND_STATS
+        {   // debug build: iterations whose child rays all leave surfaces of one kind / that hold Dielectric children at all
+            const unsigned long long cL = __ballot(is_child && ckind == kKindLambert), cM = __ballot(is_child && ckind == kKindMetal),
+                                     cD = __ballot(is_child && ckind == kKindDielectric);
+            const int kinds = (cL != 0ull) + (cM != 0ull) + (cD != 0ull);
+            if (kinds == 1) dbg_pure++;
+            if (kinds >= 1) dbg_with_children++;
+            if (cD != 0ull) dbg_with_diel++;
+        }
+#endif
         // rays by kind (wave-uniform counts)
         n_lamb += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindLambert));
         n_metal += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindMetal));
@@ -706,8 +752,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             } else overflow = true;             // beyond 64 records per level: a bug
         }
         if (top + npush <= a.nblk * 64) {
+            // ---- order of this iteration's pushes (SURVEY.md section 7 "sort/compact by surface kind at expansion").
+            // Deepest level on top, as the pool bound needs; WITHIN a level the records are grouped by the kind of the
+            // surface hit (Lambertian on top, then Metal, then Dielectric: Surface.fs:66,93,168 are three different
+            // routines), so that a later pop — 16 Lambertian records fill the 64 lanes — is mostly of one kind and the
+            // blocks of the other kinds in the generate code above are skipped as a whole instead of running for a
+            // handful of lanes (before: records in lane order, and with 76 % / 4 % / 19 % of the records Lambertian /
+            // Metal / Dielectric practically every pop held all three).  Images cannot change: sums are integer and
+            // the RNG is keyed by the tree node.  One trip per level present among the pushes (wave-uniform loop, the
+            // levels in order of their first lane: deepest first in the linear-scan kernels, whose lanes are ordered
+            // by level).
+            int rank = mbcnt64(pm);                             // from the top
+            if (kKindSort) {
+                const int hk = (int)(hinfo & 3u);
+                unsigned long long rem = pm;
+                int base = 0;
+                while (rem != 0ull) {
+                    const int lvl = __builtin_amdgcn_readlane(clevel, (int)__builtin_ctzll(rem));
+                    const bool here = push && clevel == lvl;
+                    const unsigned long long m = __ballot(here);
+                    const unsigned long long mL = __ballot(here && hk == kKindLambert), mM = __ballot(here && hk == kKindMetal);
+                    const unsigned long long mD = m & ~(mL | mM);
+                    const int nL = popc_mask(mL), nM = popc_mask(mM);
+                    if (here) {
+                        const int rL = mbcnt64(mL), rM = nL + mbcnt64(mM), rD = nL + nM + mbcnt64(mD);
+                        rank = base + ((hk == kKindLambert) ? rL : (hk == kKindMetal) ? rM : rD);
+                    }
+                    base += popc_mask(m);
+                    rem = uniform64(rem & ~m);
+                }
+            }
             if (push) {
-                const int pos = top + (npush - 1 - mbcnt64(pm));
+                const int pos = top + (npush - 1 - rank);
                 uint32_t* wb = rec_base(pos);
                 wb[F_PX] = __float_as_uint(P.x); wb[F_PY] = __float_as_uint(P.y); wb[F_PZ] = __float_as_uint(P.z);
                 wb[F_DX] = __float_as_uint(Dn.x); wb[F_DY] = __float_as_uint(Dn.y); wb[F_DZ] = __float_as_uint(Dn.z);
@@ -798,6 +874,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
             atomicMax(stats + 18, __builtin_readcyclecounter() - t_start);
+#ifdef RT_KIND_STATS
+            atomicAdd(stats + 16, (unsigned long long)dbg_pure); atomicAdd(stats + 17, (unsigned long long)dbg_with_children);
+            atomicAdd(stats + 19, (unsigned long long)dbg_with_diel);
+#endif
 #ifdef RT_WAVE_TIMES
             if (PHASE == RT_WAVE_TIMES) {   // debug build (tools/wave_times.py): when the waves of one pass start and end
                 const unsigned long long wt_end = wall_clock64();
