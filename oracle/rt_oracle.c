@@ -4,11 +4,19 @@
  * (raytracer_amd/, include/) may call, link or import it; only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg do.
  *
- * PARITY UNPINNED.  The reference (F#, .NET Core 2.0, raytracer/raytracer.fsproj:4) cannot be
- * built or run here (no .NET toolchain; its Henzai.Core project dependency,
- * raytracer.fsproj:8, is not in the tree) and it ships no tests, golden vectors or fixtures
- * for this path.  What follows therefore restates the F# line by line in float32 and fills the
- * gaps with stated assumptions:
+ * HOW IT IS PINNED.  The reference (F#, .NET Core 2.0, raytracer/raytracer.fsproj:4) cannot be built
+ * or run here (no .NET toolchain; its Henzai.Core project dependency, raytracer.fsproj:8, is not in
+ * the tree) and it ships no tests or golden vectors for this path.  It does hold five images that its own
+ * saveFrameBuffer / saveDepthBuffer (Scene.fs:123-144) wrote: depth.jpg, display.jpg, 16_4_sphere.jpg,
+ * 16_6_sphere.jpg, 4_6_sphere.jpg.  tests/golden/make_golden.py turned them into data-only fixtures and
+ *   - tests/test_golden.py holds THIS FILE to them on the CPU: the 800x640 pinhole depth buffer through the
+ *     image stage against depth.jpg (>= 45 dB, hit/miss mask >= 99.8 %: measured 48.0 dB, 99.91 %), renders at
+ *     the sample counts / trace depths the file names state against the four colour JPEGs (>= 38 dB on 8x8
+ *     box-filtered RGB: measured 40.1-40.7 dB);
+ *   - tests/test_gpu_reference_images.py holds the HIP frames to the same images.
+ * That is a SOFT pin: lossy JPEGs with unrecorded parameters catch a wrong camera, root rule, rectangle test,
+ * cull or estimator, not ulp-level choices.  Wherever a test says "bit-exact", it means bit-exact against this
+ * restatement, which fills the gaps the images cannot see with stated assumptions (PARITY UNPINNED for these):
  *   - System.Numerics (.NET Core 2.0.5, hardware-accelerated path): Dot = (x*x'+y*y')+z*z';
  *     Length = sqrt(Dot(v,v)); `Vector3 / float` multiplies by 1.0f/float; Normalize =
  *     v / Length(v) through that operator; TransformNormal / Vector4.Transform /
@@ -19,10 +27,10 @@
  *     (y up, y = r1 = cos theta; Scene.fs:1 and Surface.fs:111 cite those lessons),
  *     CreateCoordinateSystemAroundNormal = scratchapixel createCoordinateSystem,
  *     RandomInUnitSphere = rejection sampling in [-1,1]^3.  Random numbers come from the
- *     build's counter-based generator (Philox4x32-10, Random123 KATs in the tests), keyed by
+ *     build's counter-based generator (Philox4x32-10, Random123 KATs in tests/test_oracle_kat.py), keyed by
  *     (seed; pixel-sample index, ray-tree node index), so the GPU can reproduce every draw.
- * The only reference-produced data are its JPEG renders; tests/test_soft_fixture.py compares
- * this oracle's render with display.jpg as a sanity check, no more.
+ * Hand-derived known answers of the reference's formulas (tests/test_oracle_kat.py) and committed renders of this
+ * file (tests/golden/oracle_*.npz) guard it against its own regressions.
  *
  * Every function cites the reference lines it restates (paths relative to /root/reference).
  */

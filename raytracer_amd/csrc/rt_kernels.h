@@ -98,10 +98,6 @@ RT_DEV ColdPtr cold_args()
 // bits of the status word a launch leaves behind (rt_scene_status)
 constexpr uint32_t kNoPixel = 0xffffffffu;   // (frames have fewer than 2^31 pixels)
 constexpr int kPixelCacheMinSpp = 8;         // samples per pixel from which finished samples go through the pixel cache
-#ifndef RT_KIND_SORT
-#define RT_KIND_SORT 0
-#endif
-constexpr bool kKindSort = RT_KIND_SORT != 0;   // group an iteration's pushes by surface kind (trace_kernel, "order of this iteration's pushes")
 constexpr int kStatusOverflow = 1;      // a wave's record pool overflowed
 constexpr int kStatusRange = 2;         // a radiance contribution was NaN, infinite or >= 2^31 and was dropped
 
@@ -237,9 +233,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     uint32_t n_iter = 0;                        // loop iterations (wave-uniform)
     uint32_t n_lamb = 0, n_metal = 0, n_diel = 0;   // child rays intersected, by the kind that scattered them
     uint32_t n_refill = 0;                      // hand-outs this wave has taken (two-pass frames)
-#ifdef RT_KIND_STATS
-    uint32_t dbg_pure = 0, dbg_with_children = 0, dbg_with_diel = 0;
-#endif
 #ifdef RT_PHASE_TIMING
     unsigned long long ph_gen = 0, ph_scan = 0, ph_trav = 0, ph_shade = 0, ph_t = __builtin_readcyclecounter();
 #define RT_PHASE(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - ph_t; ph_t = now_; }
@@ -631,16 +624,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             }
         }
 
-#ifdef RT_KIND_STATS
-        {   // debug build: iterations whose child rays all leave surfaces of one kind / that hold Dielectric children at all
-            const unsigned long long cL = __ballot(is_child && ckind == kKindLambert), cM = __ballot(is_child && ckind == kKindMetal),
-                                     cD = __ballot(is_child && ckind == kKindDielectric);
-            const int kinds = (cL != 0ull) + (cM != 0ull) + (cD != 0ull);
-            if (kinds == 1) dbg_pure++;
-            if (kinds >= 1) dbg_with_children++;
-            if (cD != 0ull) dbg_with_diel++;
-        }
-#endif
         // rays by kind (wave-uniform counts)
         n_lamb += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindLambert));
         n_metal += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindMetal));
@@ -752,38 +735,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             } else overflow = true;             // beyond 64 records per level: a bug
         }
         if (top + npush <= a.nblk * 64) {
-            // ---- order of this iteration's pushes (SURVEY.md section 7 "sort/compact by surface kind at expansion").
-            // Deepest level on top, as the pool bound needs; WITHIN a level the records are grouped by the kind of the
-            // surface hit (Lambertian on top, then Metal, then Dielectric: Surface.fs:66,93,168 are three different
-            // routines), so that a later pop — 16 Lambertian records fill the 64 lanes — is mostly of one kind and the
-            // blocks of the other kinds in the generate code above are skipped as a whole instead of running for a
-            // handful of lanes (before: records in lane order, and with 76 % / 4 % / 19 % of the records Lambertian /
-            // Metal / Dielectric practically every pop held all three).  Images cannot change: sums are integer and
-            // the RNG is keyed by the tree node.  One trip per level present among the pushes (wave-uniform loop, the
-            // levels in order of their first lane: deepest first in the linear-scan kernels, whose lanes are ordered
-            // by level).
-            int rank = mbcnt64(pm);                             // from the top
-            if (kKindSort) {
-                const int hk = (int)(hinfo & 3u);
-                unsigned long long rem = pm;
-                int base = 0;
-                while (rem != 0ull) {
-                    const int lvl = __builtin_amdgcn_readlane(clevel, (int)__builtin_ctzll(rem));
-                    const bool here = push && clevel == lvl;
-                    const unsigned long long m = __ballot(here);
-                    const unsigned long long mL = __ballot(here && hk == kKindLambert), mM = __ballot(here && hk == kKindMetal);
-                    const unsigned long long mD = m & ~(mL | mM);
-                    const int nL = popc_mask(mL), nM = popc_mask(mM);
-                    if (here) {
-                        const int rL = mbcnt64(mL), rM = nL + mbcnt64(mM), rD = nL + nM + mbcnt64(mD);
-                        rank = base + ((hk == kKindLambert) ? rL : (hk == kKindMetal) ? rM : rD);
-                    }
-                    base += popc_mask(m);
-                    rem = uniform64(rem & ~m);
-                }
-            }
             if (push) {
-                const int pos = top + (npush - 1 - rank);
+                const int pos = top + (npush - 1 - mbcnt64(pm));
                 uint32_t* wb = rec_base(pos);
                 wb[F_PX] = __float_as_uint(P.x); wb[F_PY] = __float_as_uint(P.y); wb[F_PZ] = __float_as_uint(P.z);
                 wb[F_DX] = __float_as_uint(Dn.x); wb[F_DY] = __float_as_uint(Dn.y); wb[F_DZ] = __float_as_uint(Dn.z);
@@ -874,10 +827,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
             atomicMax(stats + 18, __builtin_readcyclecounter() - t_start);
-#ifdef RT_KIND_STATS
-            atomicAdd(stats + 16, (unsigned long long)dbg_pure); atomicAdd(stats + 17, (unsigned long long)dbg_with_children);
-            atomicAdd(stats + 19, (unsigned long long)dbg_with_diel);
-#endif
 #ifdef RT_WAVE_TIMES
             if (PHASE == RT_WAVE_TIMES) {   // debug build (tools/wave_times.py): when the waves of one pass start and end
                 const unsigned long long wt_end = wall_clock64();
