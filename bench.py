@@ -72,15 +72,18 @@ def workload_scene(wl):
 # Lambertian child, 60 per Metal child, 110 per Dielectric child and 30 per primary; the kernel counts
 # its rays by kind, so flops per launch = 437 rays + 90 nL + 60 nM + 110 nD + 30 nPrimary.
 FLOPS_SCAN, FLOPS_LAMB, FLOPS_METAL, FLOPS_DIEL, FLOPS_PRIMARY = 437.0, 90.0, 60.0, 110.0, 30.0
-# MI355X_MICROARCH.md: peak FP32 vector.  Measured with tools/valu_ops.hip (profiles/r02_valu_ops.txt): that rate is
-# reached by v_pk_fma_f32 only (two FMAs per lane every ~4.2 cycles: 147 TFLOP/s); a plain v_fma_f32 issues every ~4
-# cycles per SIMD (half the peak), v_add/v_sub/v_mul_f32 every ~2.3 cycles (one flop each: 0.42 of the peak), compares,
-# selects, min/max, conversions and integer multiplies every ~4.1 cycles, v_sqrt/v_rcp every ~8.  The render loop is
-# reference-order arithmetic without contraction, so its own ceiling is well below `peak`.
+# MI355X_MICROARCH.md: peak FP32 vector.  Measured with tools/valu_ops.hip and tools/clock_probe.hip (profiles/
+# r02_valu_ops.txt, r03_clock_probe.txt; shader clock 2.34-2.39 GHz under load): that rate is reached by v_pk_fma_f32
+# (two FMAs per lane every ~4.2 cycles: 147 TFLOP/s) and by v_fma_f32 with an inline-constant operand (2.2 cycles); a
+# v_fma_f32 with three register operands issues every 3.5-4.1 cycles per SIMD, v_add/v_sub/v_mul_f32 every ~2.2 (one
+# flop each: 0.45 of the peak), compares, selects, min/max, conversions and integer multiplies every ~4.1, v_sqrt/v_rcp
+# every ~8.  The render loop is reference-order arithmetic without contraction, so its own ceiling is well below `peak`
+# (DESIGN.md section 6).
 VALU_PEAK_TFLOPS = 157.3
-PEAK_NOTE = ("157.3 TFLOP/s is v_pk_fma_f32 (measured 147); reference-order f32 arithmetic without "
-             "contraction issues v_add/v_mul at ~2.3 and compares/selects/min/max/fma at ~4.1 cycles "
-             "per wave64 instruction per SIMD (profiles/r02_valu_ops.txt, DESIGN.md section 6)")
+PEAK_NOTE = ("157.3 TFLOP/s is v_pk_fma_f32 (measured 147) or v_fma_f32 with two register operands and a constant; "
+             "reference-order f32 arithmetic without contraction issues v_add/v_mul at 2.2, three-register fma at 3.5-4.1 and "
+             "compares/selects/min/max at 4.1 cycles per wave64 instruction per SIMD, at a shader clock measured at "
+             "2.34-2.39 GHz under load (profiles/r03_clock_probe.txt, r02_valu_ops.txt, DESIGN.md section 6)")
 
 
 # BVH scenes: 20 flops per box test (four per visit of a 4-wide node), 40 per triangle test, 27

@@ -10,9 +10,12 @@
 // fixed point, so the image does not depend on the order in which rays happen to be traced
 // (run-to-run, across wave counts and across multi-GPU partitions the output is bit-identical).
 //
-// Work distribution: pixel-samples are numbered 0..total-1 (sample-minor, then py, then column);
-// a wave pulls them in chunks of 64 from one global counter whenever its pool runs dry, so all waves
-// finish together whatever the cost of individual pixels (1 ray for a light, thousands for the floor).
+// Work distribution: pixel-samples are handed out by position in a fixed order — pixel-major for large frames (the samples
+// of a pixel arrive together), sample-major in one strip of columns per XCD for medium frames, two passes over a list of
+// primary hit records for small ones (`PHASE`, below) — with consecutive positions mapped to pixels far apart in the
+// image.  A wave takes exactly as many positions as it has free lanes (at most 32) with one returning atomic whenever its
+// pool runs dry, so all waves finish together whatever the cost of individual pixels (1 ray for a light, thousands for
+// the floor).
 //
 // Pool: a LIFO of HIT RECORDS (hit point, incoming direction, beta, surface, tree node).  A record
 // with n children is expanded lazily: each iteration takes the top records whose children fit in

@@ -38,6 +38,7 @@ class Scene:
         self.rayCount = 0
         self._lib = None
         self._scene = C.c_void_p()
+        self._pinned = False
 
     # -- plumbing ---------------------------------------------------------------------------
     def params(self, x_begin=0, x_end=None, x_step=1):
@@ -53,8 +54,14 @@ class Scene:
         self._lib = abi.load_hip_library()
         arr = host.flatten_surfaces(self.surfaces)
         abi.check(self._lib, self._lib.rt_scene_create(arr, len(self.surfaces), self.device, C.byref(self._scene)))
-        # the frame buffers move to pinned host memory (rt_host_alloc), so that rt_render copies into them by DMA; the
-        # arrays keep their block alive for as long as anyone holds them (abi.PinnedBlock)
+        return self._scene
+
+    def _pin_buffers(self):
+        """The frame buffers move to pinned host memory (rt_host_alloc) before the first render into them, so that
+        rt_render copies by DMA; the arrays keep their block alive for as long as anyone holds them (abi.PinnedBlock)."""
+        if self._pinned:
+            return
+        self._pinned = True
         try:
             for name in ("frameBuffer", "depthBuffer", "objectIds"):
                 old = getattr(self, name)
@@ -63,7 +70,6 @@ class Scene:
                 setattr(self, name, new)
         except abi.RtError:
             pass                  # pageable buffers work too, only slower
-        return self._scene
 
     def close(self):
         if self._scene:
@@ -79,6 +85,7 @@ class Scene:
     # -- Scene.fs:117-121 -------------------------------------------------------------------
     def renderScene(self):
         self.upload()
+        self._pin_buffers()
         p = self.params()
         md, rays = C.c_float(0.0), C.c_uint64(0)
         abi.check(self._lib, self._lib.rt_render(self._scene, C.byref(self.camera), C.byref(p),
@@ -127,6 +134,7 @@ class Scene:
         scenes = [self] + list(others)
         for s in scenes:
             s.upload()
+        self._pin_buffers()
         arr = (C.c_void_p * len(scenes))(*[s._scene for s in scenes])
         p = self.params()
         md, rays = C.c_float(0.0), C.c_uint64(0)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# all round-2 profiles in one go: tools/prof_all.sh <tag> "<workloads>"
+# all profiles of a round in one go: tools/prof_all.sh <tag> "<workloads>"
 set -u
 TAG=$1; WLS=$2
 for wl in $WLS; do
