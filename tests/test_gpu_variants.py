@@ -138,6 +138,21 @@ def test_one_pass_hand_out_orders(spp, depth, mesh):
                    jitter=1, seed=21, two_pass=1, lambertian_samples=2 if depth > 4 else 0))
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 1), (1, 7), (9, 1), (5, 3), (17, 13), (64, 1)])
+def test_strips_per_xcd_on_frames_smaller_than_the_strip_count(w, h):
+    """A sample-major one-pass frame is cut into one strip of columns per XCD, each with its own hand-out counter
+    (trace_kernel, take()): frames of fewer pixels than strips, strips of one pixel, a shorter last strip and strips
+    without any pixel must all hand out every pixel-sample exactly once (the ray count says so) and give the oracle's
+    frame; interleaved column shares of such a frame likewise."""
+    s = Scene(width=w, height=h, samplesPerPixel=5, maxTraceDepth=3, jitter=1, seed=9, two_pass=1)
+    _compare(s)
+    if w >= 3:
+        full = s.frameBuffer.copy()
+        for r in range(3):
+            rgba, _, _, _, _ = s.renderColumns(r, w, 3)
+            assert np.array_equal(rgba, full[r::3])
+
+
 def test_two_pass_column_partition_and_empty_regions():
     """Interleaved columns of a two-pass frame equal the full frame; a scene that is mostly sky (list chunks without a
     single valid entry) terminates with the right image."""
