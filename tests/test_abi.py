@@ -62,6 +62,8 @@ def test_no_cpu_fallback_without_a_device():
     rc = lib.rt_scene_create(arr, 12, 0, C.byref(scene))
     assert rc == abi.RT_E_NO_DEVICE and not scene
     assert b"no HIP device" in lib.rt_last_error()
+    ptr = C.c_void_p()
+    assert lib.rt_host_alloc(4096, C.byref(ptr)) == abi.RT_E_NO_DEVICE and not ptr      # no pinned memory without a device either
     from raytracer_amd.scene import Scene
     with pytest.raises(abi.RtError):
         Scene(width=8, height=8).renderScene()
@@ -74,6 +76,10 @@ def test_argument_validation_messages():
     assert lib.rt_find_closest(None, 0, None, None, None, None) == abi.RT_E_INVALID
     assert lib.rt_render_multi(None, 0, None, None, None, None, None, None, None) == abi.RT_E_INVALID
     assert lib.rt_render_device_noalloc(None, None, None, None, None, None, None, None) == abi.RT_E_INVALID
+    assert lib.rt_host_alloc(4096, None) == abi.RT_E_INVALID
+    ptr = C.c_void_p(1)
+    assert lib.rt_host_alloc(0, C.byref(ptr)) == abi.RT_E_INVALID and not ptr
+    lib.rt_host_free(None)                                                              # like free(NULL)
 
 
 def test_product_does_not_reference_the_oracle():
