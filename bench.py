@@ -188,6 +188,12 @@ def main():
               f"or under torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
 
+    # The contract is ONE JSON line on stdout.  Libraries chat there too (gloo prints its connection report to stdout):
+    # from here on file descriptor 1 is stderr, and the JSON line is written to the real stdout at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi, multi
@@ -390,7 +396,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -234,6 +234,7 @@ constexpr int kBvhGroupShift = RT_BVH_GROUP_SHIFT;
 #define RT_LIN_GROUP_SHIFT 2
 #endif
 constexpr int kLinGroupShift = RT_LIN_GROUP_SHIFT;
+constexpr size_t kStripTreeBytes = 32u << 20;   // trees below this stay in one strip (launch of a sample-major frame)
 constexpr int kDeepTrace = 8;           // maxTraceDepth above which the samples of a pixel are not kept together (launch_trace)
 constexpr long long kSampleMajorBelow = RT_SAMPLE_MAJOR_BELOW;   // pixel-samples per wave below which a one-pass frame is handed out sample-major
 
@@ -497,7 +498,12 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
         // a wave's share of the frame is small enough for one heavy refill to matter: sample-major hand-out (4K frames
         // keep the samples of a pixel together: they meet in the pixel cache, and their tail is under 1 % of the frame)
         // ... in one strip of columns per XCD (trace_kernel, take()): the permutation works inside a strip
-        c.part_pixels = (unsigned int)((npix + kXcdParts - 1) / kXcdParts);
+        // (a tree that an XCD's L2 mostly holds gains nothing from the strips and loses 1 % to their imbalance — the
+        // 100k-triangle mesh, 7.6 MB, 83 % L2 hits: one strip then, i.e. the other seven are empty and every wave
+        // moves to the first at once; measured: profiles/r03_experiments.txt section 3)
+        const size_t tree_bytes = sc->use_bvh ? (size_t)sc->pdata_off + (size_t)sc->nprims * 48 : 0;
+        const int strips = (sc->use_bvh && tree_bytes < kStripTreeBytes) ? 1 : kXcdParts;
+        c.part_pixels = (unsigned int)((npix + strips - 1) / strips);
         c.part_items = c.part_pixels * (unsigned int)p->spp;
         c.scatter = multiplier(c.part_pixels);
         c.scatter_tail = multiplier((unsigned long long)npix % c.part_pixels);      // (0 when the strips are all full)

@@ -48,7 +48,8 @@ def spawn_ranks(argv, world, port=None, grace_s=15.0, poll_s=0.05, timeout_s=Non
     if world < 1:
         raise ValueError("world must be >= 1")
     port = free_port() if port is None else port
-    procs = [subprocess.Popen(list(argv), env=rank_env(r, world, port)) for r in range(world)]
+    # rank 0 owns the parent's stdout (the JSON line); whatever the other ranks print there goes to stderr
+    procs = [subprocess.Popen(list(argv), env=rank_env(r, world, port), stdout=None if r == 0 else 2) for r in range(world)]       # (2 = this process's stderr descriptor)
     first_bad, failed_at, t0 = 0, None, time.monotonic()
     try:
         while True:
