@@ -89,3 +89,17 @@ def test_fsproj_keeps_the_reference_compile_order():
            "Geometry/AABB.fs", "Surface.fs", "SceneDefinitions.fs", "Scene.fs", "Program.fs"]      # raytracer.fsproj:11-21
     assert [f for f in order if f in ref] == ref
     assert order.index("SceneDefinitions.fs") < order.index("Native.fs") < order.index("SceneGpu.fs") < order.index("Program.fs")
+
+
+def test_frame_buffers_of_the_shim_are_pinned_arrays_with_the_reference_indexer():
+    """SceneGpu keeps frameBuffer / depthBuffer (Scene.fs:28-29) in PinnedArray2D (rt_host_alloc memory): the type must
+    offer the `.[px,py]` indexer over px*height + py that saveFrameBuffer / saveDepthBuffer use (Scene.fs:128,139), free
+    its block, and the render calls must pass its pointer."""
+    gpu = open(os.path.join(ROOT, "fsharp", "SceneGpu.fs")).read()
+    assert "type PinnedArray2D<'T when 'T : unmanaged>" in NATIVE
+    assert "rt_host_alloc(bytes, &ptr)" in NATIVE and "rt_host_free ptr" in NATIVE
+    assert "member self.Item" in NATIVE and NATIVE.count("(px * height + py)") == 2
+    for buf in ("frameBuffer", "depthBuffer", "objectIds"):
+        assert re.search(r"let %s = new PinnedArray2D<" % buf, gpu), buf
+        assert "%s.Pointer" % buf in gpu
+        assert "(%s :> IDisposable).Dispose ()" % buf in gpu

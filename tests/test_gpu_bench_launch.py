@@ -46,6 +46,31 @@ def test_two_self_launched_ranks_share_one_gpu_and_gather_the_frame():
     assert two["gather_ms"] > 0 and two["value"] > 0
 
 
+def test_bench_line_carries_the_contract():
+    """One JSON line on stdout with the keys the driver reads, the roofline and the CPU baseline (the oracle timed on
+    the host cores, a bounded sample), and nothing else on stdout."""
+    r = _bench("--workload", "c1", "--steps", "3", "--warmup", "1", "--no-extra")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["config"]["workload"].startswith("c1:") and d["config"]["rays_per_frame"] == 16886754
+    roof = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"):
+        assert key in roof, key
+    assert roof["peak"] == 157.3 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.0 < roof["frac"] < 1.0
+    # value = rays of all frames / wall time of the timed region; the kernel bracket is inside it
+    assert abs(d["value"] - d["config"]["rays_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-9
+    assert roof["kernel_ms"] <= d["ms_per_step"]
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "Mrays/s" and cpu["value"] > 0 and "640x480" in cpu["sample"]
+
+
 def test_asking_for_more_gpus_than_the_box_has_is_a_message_not_a_traceback():
     n = _ndev() + 1
     r = _bench("--gpus", str(n), "--workload", "c1", "--steps", "1")
