@@ -2,6 +2,8 @@
 (with and without a small mesh), every estimator / pass / ring / sample-count / depth / background combination the draw
 produces, odd frame sizes, and a random column partition.  Bit-exact object IDs, depth, hit mask and ray count, RGB
 within 1e-4 (tests/test_gpu_parity.py::_compare)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -30,9 +32,14 @@ def _random_scene(rng):
     return np.concatenate(parts)
 
 
-@pytest.mark.parametrize("case", range(14))
+# RT_FUZZ_CASES / RT_FUZZ_BASE in the environment widen the draw for a one-off soak (the committed default stays small)
+_CASES = int(os.environ.get("RT_FUZZ_CASES", "14"))
+_BASE = int(os.environ.get("RT_FUZZ_BASE", "1000"))
+
+
+@pytest.mark.parametrize("case", range(_CASES))
 def test_random_scene_and_parameters(case):
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(_BASE + case)
     surfaces = _random_scene(rng)
     estimator = int(rng.random() < 0.35)
     depth = int(rng.choice([0, 1, 2, 3, 4, 5, 14])) if estimator or rng.random() < 0.5 else int(rng.choice([0, 1, 2, 3, 4]))
