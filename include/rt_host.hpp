@@ -260,6 +260,7 @@ public:
     Vector3 backgroundColor{ 0.0f, 0.0f, 0.0f };                                  // Scene.fs:32
     Vector3 cameraOriginWS{ -3.0f, 6.0f, 15.0f }, lookAt{ -1.0f, 1.0f, -10.0f };   // Scene.fs:36-37
     uint64_t seed = 1; int jitter = 1, device = 0;
+    std::vector<int> devices;                // empty = {device}; several = one share of interleaved columns per device (rt_render_multi)
     int estimator = RT_ESTIMATOR_BRANCHING;  // RT_ESTIMATOR_SINGLE_PATH: one child per hit, Dielectric.Scatter (Surface.fs:155-166)
     int lambertianSamples = 0;               // 0 = Surface.fs:63 (4)
     std::vector<Surface> surfaces;                                                // Scene.fs:33
@@ -271,16 +272,41 @@ public:
 
     explicit Scene(std::vector<Surface> s) : surfaces(std::move(s)) {}
     Scene() : surfaces(SceneDefinitions().scene_spheres) {}
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+    ~Scene() { release(); }
+
+    // `scene_spheres |> Array.ofList` (Scene.fs:33) happens ONCE: the flattened scene (and, for large scenes, the BVH
+    // built inside rt_scene_create) is uploaded to the HBM of every device used and kept until the surfaces are
+    // replaced (call release()) or the object dies; renderScene() only renders.
+    void upload()
+    {
+        if (!handles_.empty()) return;
+        const std::vector<rt_surface> flat = flatten(surfaces);
+        const std::vector<int> devs = devices.empty() ? std::vector<int>{ device } : devices;
+        for (int d : devs) {
+            rt_scene* sc = nullptr;
+            if (rt_scene_create(flat.data(), (int64_t)flat.size(), d, &sc) != RT_OK) {
+                const std::string err = rt_last_error();
+                release();
+                throw std::runtime_error(err);
+            }
+            handles_.push_back(sc);
+        }
+    }
+    void release()
+    {
+        for (rt_scene* sc : handles_) rt_scene_destroy(sc);
+        handles_.clear();
+    }
 
     // Scene.fs:117-121.  Throws like the reference's failwith on any error of the library.
     void renderScene()
     {
+        upload();
         frameBuffer.assign((size_t)width * height * 4, 0.0f);
         depthBuffer.assign((size_t)width * height, std::numeric_limits<float>::max());
         objectIds.assign((size_t)width * height, 0);
-        const std::vector<rt_surface> flat = flatten(surfaces);
-        rt_scene* sc = nullptr;
-        if (rt_scene_create(flat.data(), (int64_t)flat.size(), device, &sc) != RT_OK) throw std::runtime_error(rt_last_error());
         const rt_camera cam = make_camera(cameraOriginWS, lookAt);
         rt_params p;
         std::memset(&p, 0, sizeof p);
@@ -288,10 +314,11 @@ public:
         p.background[0] = backgroundColor.X; p.background[1] = backgroundColor.Y; p.background[2] = backgroundColor.Z;
         p.jitter = jitter; p.seed = seed; p.x_begin = 0; p.x_end = width; p.x_step = 1;
         p.estimator = estimator; p.lambertian_samples = lambertianSamples;
-        const int rc = rt_render(sc, &cam, &p, frameBuffer.data(), depthBuffer.data(), objectIds.data(), &maxFrameBufferDepth, &rayCount);
-        const std::string err = rc == RT_OK ? "" : rt_last_error();
-        rt_scene_destroy(sc);
-        if (rc != RT_OK) throw std::runtime_error(err);
+        const int rc = handles_.size() == 1
+            ? rt_render(handles_[0], &cam, &p, frameBuffer.data(), depthBuffer.data(), objectIds.data(), &maxFrameBufferDepth, &rayCount)
+            : rt_render_multi(handles_.data(), (int32_t)handles_.size(), &cam, &p, frameBuffer.data(), depthBuffer.data(), objectIds.data(),
+                              &maxFrameBufferDepth, &rayCount);
+        if (rc != RT_OK) throw std::runtime_error(rt_last_error());
     }
 
     // ---- Scene.fs:123-144: the image stage.  ImageSharp's JPEG encoder is replaced by binary PPM (P6); everything up
@@ -332,6 +359,8 @@ public:
     void saveDepthBuffer(const std::string& path = "depth.ppm") const { writePpm(path, depthBufferImage()); }      // Scene.fs:134-144
 
 private:
+    std::vector<rt_scene*> handles_;       // one per device, created by upload()
+
     void writePpm(const std::string& path, const std::vector<uint8_t>& rgba) const
     {
         FILE* f = std::fopen(path.c_str(), "wb");

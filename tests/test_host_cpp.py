@@ -72,14 +72,18 @@ def test_cpp_save_frame_and_depth_buffer_pack_like_the_python_image_stage(tmp_pa
 
 
 @pytest.mark.gpu
-def test_cpp_render_scene_matches_python_scene(tmp_path):
+@pytest.mark.parametrize("shares", [1, 3])
+def test_cpp_render_scene_matches_python_scene(tmp_path, shares):
+    """raytracer::Scene::renderScene through rt_render (one handle) and rt_render_multi (three handles, interleaved
+    columns), twice on handles uploaded once: the frame the Python Scene gets."""
     from raytracer_amd.scene import Scene
     exe = os.path.join(HERE, "render_scene")
     if not os.path.exists(exe):
         exe = _build("render_scene")
     w, h, spp, depth, jitter = 96, 72, 2, 4, 1
     out = tmp_path / "frame.bin"
-    subprocess.run([exe, str(w), str(h), str(spp), str(depth), str(jitter), str(out)], check=True, timeout=120)
+    subprocess.run([exe, str(w), str(h), str(spp), str(depth), str(jitter), str(out)] + ([str(shares)] if shares > 1 else []),
+                   check=True, timeout=120)
     raw = out.read_bytes()
     n = w * h
     fb = np.frombuffer(raw, dtype=np.float32, count=n * 4).reshape(w, h, 4)
