@@ -26,6 +26,10 @@ struct BvhRef {
     const float4* __restrict__ nodes;     // 8 float4 per node, followed in the same allocation by the primitive records
     uint32_t pdata_off;                   // byte offset of the records (3 float4 per primitive slot) from `nodes`
     int nnodes;
+    // spheres in the tree: the ray is walked as a cone (closest_hit_bvh).  cone_k = bound of the sphere test's rounding error
+    // per squared distance (0: no spheres), rmin / rmax = smallest / largest radius, reach = sum over the axes of the
+    // largest |coordinate| of the root box (|c - O| <= reach + |O|_1 for every centre c)
+    float cone_k, rmin, rmax, reach;
 };
 
 constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a leaf ref)
@@ -59,6 +63,9 @@ RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef RT_BVH_PACK_OFF
+#define RT_BVH_PACK_OFF 1     // 0: A/B build, six offset registers and seven selects per round
+#endif
 
 // Slab tests of two boxes at once (v_pk_fma_f32); returns the entry parameters, kFltMax when missed.
 // `near*` / `far*` are the box planes the ray meets first / last on each axis (chosen by the sign of the
@@ -75,16 +82,46 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // (tests/test_gpu_bvh.py::test_find_closest_unit_scale_mesh_from_far_origins).  Per axis on purpose: a single slack of
 // max_k |O_k / D_k| accepts every box within reach for a ray with one small direction component (measured: 1M spheres
 // -22 %).
-RT_DEV void box_entry2(v2f nearx, v2f neary, v2f nearz, v2f farx, v2f fary, v2f farz, f3 inv, f3 noi_lo, f3 noi_hi, float tmax, float& ta, float& tb)
+// (v_pk_fma_f32 reads a 64-bit register pair per operand; op_sel / op_sel_hi pick, per result half, which half of the pair
+// is used.  The compiler does not use them for a broadcast: it builds a pair {c, c} per constant — 24 registers for the
+// twelve per-ray constants of the slab test.  Written by hand, the near constant of an axis lives in the low half of a
+// pair and the far constant in the high half: 12 registers.)
+#ifndef RT_BVH_PK_ASM
+#define RT_BVH_PK_ASM 1       // 0: A/B build, the compiler's own pairs
+#endif
+RT_DEV v2f pk_fma_bcast_lo(v2f a, v2f m, v2f c)
 {
-    const v2f ix = { inv.x, inv.x }, iy = { inv.y, inv.y }, iz = { inv.z, inv.z };
-    const v2f nx = { noi_lo.x, noi_lo.x }, ny = { noi_lo.y, noi_lo.y }, nz = { noi_lo.z, noi_lo.z };
-    const v2f fx = { noi_hi.x, noi_hi.x }, fy = { noi_hi.y, noi_hi.y }, fz = { noi_hi.z, noi_hi.z };
-    const v2f x0 = __builtin_elementwise_fma(nearx, ix, nx), x1 = __builtin_elementwise_fma(farx, ix, fx);
-    const v2f y0 = __builtin_elementwise_fma(neary, iy, ny), y1 = __builtin_elementwise_fma(fary, iy, fy);
-    const v2f z0 = __builtin_elementwise_fma(nearz, iz, nz), z1 = __builtin_elementwise_fma(farz, iz, fz);
-    const float tna = fmaxf(fmaxf(x0.x, y0.x), fmaxf(z0.x, 0.0f)), tfa = fminf(fminf(x1.x, y1.x), fminf(z1.x, tmax));
-    const float tnb = fmaxf(fmaxf(x0.y, y0.y), fmaxf(z0.y, 0.0f)), tfb = fminf(fminf(x1.y, y1.y), fminf(z1.y, tmax));
+    v2f r;
+    if (!RT_BVH_PK_ASM) return __builtin_elementwise_fma(a, v2f{ m.x, m.x }, v2f{ c.x, c.x });
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(m), "v"(c));
+    return r;
+}
+RT_DEV v2f pk_fma_bcast_hi(v2f a, v2f m, v2f c)
+{
+    v2f r;
+    if (!RT_BVH_PK_ASM) return __builtin_elementwise_fma(a, v2f{ m.y, m.y }, v2f{ c.y, c.y });
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(m), "v"(c));
+    return r;
+}
+// m* = { reciprocal for the near planes, reciprocal for the far planes } of an axis, c* = { addend near, addend far }
+RT_DEV void box_entry2(v2f nearx, v2f neary, v2f nearz, v2f farx, v2f fary, v2f farz, v2f mx, v2f my, v2f mz, v2f cx, v2f cy, v2f cz, float tmax, float& ta, float& tb)
+{
+    const v2f x0 = pk_fma_bcast_lo(nearx, mx, cx), x1 = pk_fma_bcast_hi(farx, mx, cx);
+    const v2f y0 = pk_fma_bcast_lo(neary, my, cy), y1 = pk_fma_bcast_hi(fary, my, cy);
+    const v2f z0 = pk_fma_bcast_lo(nearz, mz, cz), z1 = pk_fma_bcast_hi(farz, mz, cz);
+    float tna, tfa, tnb, tfb;
+    if (RT_BVH_PK_ASM) {
+        // (the compiler does not know that the result of an asm statement is not a signalling NaN and would put a
+        // canonicalising v_max x, x in front of every fmaxf / fminf that takes one: the maxima and minima are written out too)
+        float m;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x0.x), "v"(y0.x), "v"(z0.x)); asm("v_max_f32_e32 %0, 0, %1" : "=v"(tna) : "v"(m));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x0.y), "v"(y0.y), "v"(z0.y)); asm("v_max_f32_e32 %0, 0, %1" : "=v"(tnb) : "v"(m));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x1.x), "v"(y1.x), "v"(z1.x)); asm("v_min_f32_e32 %0, %1, %2" : "=v"(tfa) : "v"(m), "v"(tmax));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(x1.y), "v"(y1.y), "v"(z1.y)); asm("v_min_f32_e32 %0, %1, %2" : "=v"(tfb) : "v"(m), "v"(tmax));
+    } else {
+        tna = fmaxf(fmaxf(x0.x, y0.x), fmaxf(z0.x, 0.0f)); tfa = fminf(fminf(x1.x, y1.x), fminf(z1.x, tmax));
+        tnb = fmaxf(fmaxf(x0.y, y0.y), fmaxf(z0.y, 0.0f)); tfb = fminf(fminf(x1.y, y1.y), fminf(z1.y, tmax));
+    }
     // the |t| share of the rounding error, both sides at once
     ta = (tna * 0.999998f <= tfa) ? tna : kFltMax;
     tb = (tnb * 0.999998f <= tfb) ? tnb : kFltMax;
@@ -161,14 +198,73 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
                             uint32_t& nodes_visited, uint32_t& prims_tested, uint32_t& rounds_inner, uint32_t& rounds_leaf)
 {
     static_assert((K & (K - 1)) == 0, "ring size must be a power of two");
-    // reciprocal direction for the slab test only (not on the exact path): v_rcp_f32 is enough
-    const f3 inv = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
-    const f3 noi = F3(-(O.x * inv.x), -(O.y * inv.y), -(O.z * inv.z));
-    const f3 noi_lo = F3(noi.x - 1e-6f * fabsf(noi.x), noi.y - 1e-6f * fabsf(noi.y), noi.z - 1e-6f * fabsf(noi.z));
-    const f3 noi_hi = F3(noi.x + 1e-6f * fabsf(noi.x), noi.y + 1e-6f * fabsf(noi.y), noi.z + 1e-6f * fabsf(noi.z));
-    // byte offsets, inside a node, of the planes met first / last on each axis (lo.x lo.y lo.z hi.x hi.y hi.z)
+    // The ray as a cone.  The reference's sphere test (Sphere.fs:18-43, prim_test) computes d = b^2 - C from two numbers
+    // of size L^2, L = |O - centre|: 15 roundings of relative 2^-24 on terms <= L^2, and |D|^2 - 1 (<= 2.4e-7 for a
+    // direction normalised in f32), put up to k L^2, k = 1.2e-6, between d and its exact value.  So the linear scan accepts
+    // a sphere that the ray passes at up to sqrt(r^2 + k L^2) from its centre, and reports the hit up to that far in
+    // front of it: 500 units away a sphere of radius 0.2 is "hit" out to 0.58.  (Measured with exact boxes: 14 of 40 000
+    // far, grazing rays over the 1M-sphere scene and 1 of 40 000 random ones got a different answer from the tree than
+    // from the scan.)  A tree that holds spheres is therefore walked with boxes that grow along the ray: by
+    // s (t + t0) on every side at parameter t, where
+    //   s  = (sqrt(rmin^2 + k Lc^2) - rmin) / Lc   the largest growth any sphere needs, per unit of distance, up to the
+    //        distance Lc beyond which this ray needs no sphere (its current hit, or the far end of the tree): the growth
+    //        sqrt(r^2 + k L^2) - r is convex in L and largest for the smallest radius;
+    //   t0 = 2.5 sqrt(rmax^2 + k Lc^2)             (the hit may lie that far before the closest approach).
+    // A near plane is then reached at (plane -+ s t0 - O) / (|D| + s) and a far plane left at (plane +- s t0 - O) /
+    // (|D| - s): the same two multiply-adds per plane pair as the plain slab test, with two sets of constants.  On an
+    // axis where |D| <= s the cone's edge never passes the far plane in the ray's direction: it moves the other way, at
+    // most (s - |D|) tcap by the end of the ray, so that edge is held at its final position: boxes beyond it are
+    // missed, the others never left on this axis.  With k = 0 (a tree of triangles: their test is off by ~1e-7 L,
+    // inside the host's padding) all of this IS the plain slab test.
+    // reciprocals for the slab test only (not on the exact path): v_rcp_f32 is enough
+    f3 inv_n, inv_f, noi_lo, noi_hi;
+    if (bvh.cone_k == 0.0f) {
+        // the plain slab test: one reciprocal per axis (a zero component gives infinities and NaNs, which max / min ignore)
+        inv_n = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
+        inv_f = inv_n;
+        const f3 noi = F3(-(O.x * inv_n.x), -(O.y * inv_n.y), -(O.z * inv_n.z));
+        noi_lo = F3(noi.x - 1e-6f * fabsf(noi.x), noi.y - 1e-6f * fabsf(noi.y), noi.z - 1e-6f * fabsf(noi.z));
+        noi_hi = F3(noi.x + 1e-6f * fabsf(noi.x), noi.y + 1e-6f * fabsf(noi.y), noi.z + 1e-6f * fabsf(noi.z));
+    } else {
+        const float tcap = fminf(tmin, (bvh.reach + (fabsf(O.x) + fabsf(O.y) + fabsf(O.z))) * 1.001f + 4.0f * bvh.rmax);
+        const float lc = tcap * 1.01f + 4.0f * bvh.rmax + 1e-20f;
+        const float e = bvh.cone_k * lc * lc;
+        const float cs = 1.02f * e * __builtin_amdgcn_rcpf((__builtin_sqrtf(bvh.rmin * bvh.rmin + e) + bvh.rmin) * lc);
+        const float ct = cs * 2.5f * __builtin_sqrtf(bvh.rmax * bvh.rmax + e);
+        auto axis = [&](float o, float dk, float& in, float& jf, float& nlo, float& nhi) {
+            const float ak = fabsf(dk);
+            const bool leaves = ak > cs;                    // the cone's trailing edge moves in the ray's direction on this axis
+            const float sh = __builtin_copysignf(ct, dk);
+            in = __builtin_copysignf(__builtin_amdgcn_rcpf(ak + cs), dk);
+            const float nn = -((o + sh) * in);
+            nlo = nn - 1e-6f * fabsf(nn);
+            if (leaves) {
+                jf = __builtin_copysignf(__builtin_amdgcn_rcpf(ak - cs), dk);
+                const float nf = -((o - sh) * jf);
+                nhi = nf + 1e-6f * fabsf(nf);
+            } else {
+                // far value = (plane - edge) * 1e30 in the ray's direction: +-huge, i.e. never left / missed
+                const float out = ct + tcap * (cs - ak);
+                const float edge = o - __builtin_copysignf(out + 1e-5f * (fabsf(o) + out), dk);
+                jf = __builtin_copysignf(1e30f, dk);
+                nhi = -(edge * jf);
+            }
+        };
+        axis(O.x, D.x, inv_n.x, inv_f.x, noi_lo.x, noi_hi.x);
+        axis(O.y, D.y, inv_n.y, inv_f.y, noi_lo.y, noi_hi.y);
+        axis(O.z, D.z, inv_n.z, inv_f.z, noi_lo.z, noi_hi.z);
+    }
+    const v2f mx = { inv_n.x, inv_f.x }, my = { inv_n.y, inv_f.y }, mz = { inv_n.z, inv_f.z };
+    const v2f cx = { noi_lo.x, noi_hi.x }, cy = { noi_lo.y, noi_hi.y }, cz = { noi_lo.z, noi_hi.z };
+    const f3 inv = inv_n;
+    // byte offsets, inside a node, of the planes met first / last on each axis (lo.x lo.y lo.z hi.x hi.y hi.z), one byte
+    // each, in the order of the seven loads: near x, far x, near y | far y, near z, far z, references.  (Two registers
+    // instead of six, and issue() selects between the node's and the leaf's offsets with two selects instead of seven.)
+    static_assert(node_row(6) < 256u, "offsets inside a node are packed into bytes");
     const uint32_t onx = (inv.x < 0.0f) ? node_row(3) : node_row(0), ony = (inv.y < 0.0f) ? node_row(4) : node_row(1), onz = (inv.z < 0.0f) ? node_row(5) : node_row(2);
     const uint32_t ofx = (node_row(0) + node_row(3)) - onx, ofy = (node_row(1) + node_row(4)) - ony, ofz = (node_row(2) + node_row(5)) - onz;
+    const uint32_t in_off0 = onx | (ofx << 8) | (ony << 16), in_off1 = ofy | (onz << 8) | (ofz << 16) | (node_row(6) << 24);
+    constexpr uint32_t kLeafOff0 = 0u | (16u << 8) | (32u << 16), kLeafOff1 = 0u | (16u << 8) | (32u << 16) | (32u << 24);
     const char* const node_bytes = reinterpret_cast<const char*>(bvh.nodes);
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kBvhDone;
@@ -215,8 +311,14 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
                 o0 = bvh.pdata_off + first * 48u;              // 48-byte records
                 o1 = o0 + (((cur & 6u) != 0u) ? 48u : 0u);
             }
+#if RT_BVH_PACK_OFF
+            const uint32_t f0 = do_in ? in_off0 : kLeafOff0, f1 = do_in ? in_off1 : kLeafOff1;
+            const uint32_t a0 = o0 + (f0 & 0xffu), a1 = o0 + ((f0 >> 8) & 0xffu), a2 = o0 + ((f0 >> 16) & 0xffu);
+            const uint32_t a3 = o1 + (f1 & 0xffu), a4 = o1 + ((f1 >> 8) & 0xffu), a5 = o1 + ((f1 >> 16) & 0xffu), a6 = o1 + (f1 >> 24);
+#else
             const uint32_t a0 = o0 + (do_in ? onx : 0u), a1 = o0 + (do_in ? ofx : 16u), a2 = o0 + (do_in ? ony : 32u);
             const uint32_t a3 = o1 + (do_in ? ofy : 0u), a4 = o1 + (do_in ? onz : 16u), a5 = o1 + (do_in ? ofz : 32u), a6 = o1 + (do_in ? node_row(6) : 32u);
+#endif
             d[0] = *reinterpret_cast<const float4*>(node_bytes + a0); d[1] = *reinterpret_cast<const float4*>(node_bytes + a1);
             d[2] = *reinterpret_cast<const float4*>(node_bytes + a2); d[3] = *reinterpret_cast<const float4*>(node_bytes + a3);
             d[4] = *reinterpret_cast<const float4*>(node_bytes + a4); d[5] = *reinterpret_cast<const float4*>(node_bytes + a5);
@@ -235,9 +337,9 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             float t0, t1, t2, t3;
             box_entry2(v2f{ nx4.x, nx4.y }, v2f{ ny4.x, ny4.y }, v2f{ nz4.x, nz4.y }, v2f{ fx4.x, fx4.y }, v2f{ fy4.x, fy4.y }, v2f{ fz4.x, fz4.y },
-                       inv, noi_lo, noi_hi, tmin, t0, t1);
+                       mx, my, mz, cx, cy, cz, tmin, t0, t1);
             box_entry2(v2f{ nx4.z, nx4.w }, v2f{ ny4.z, ny4.w }, v2f{ nz4.z, nz4.w }, v2f{ fx4.z, fx4.w }, v2f{ fy4.z, fy4.w }, v2f{ fz4.z, fz4.w },
-                       inv, noi_lo, noi_hi, tmin, t2, t3);
+                       mx, my, mz, cx, cy, cz, tmin, t2, t3);
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
             sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
             // the hits are a prefix of the sorted four: descend into the nearest, push the others far to near (below).

@@ -158,6 +158,7 @@ struct rt_scene {
     float4* d_nodes = nullptr;                 // the BVH: nodes, then the primitive records (one allocation, 32-bit offsets)
     uint32_t pdata_off = 0;                    // byte offset of the records
     int nnodes = 0, bvh_depth = 0;
+    float cone_k = 0.0f, tree_rmin = 0.0f, tree_rmax = 0.0f, tree_reach = 0.0f;    // spheres in the tree: how the traversal widens the ray (rt_bvh.h closest_hit_bvh)
     int64_t nprims = 0;                        // primitives in the BVH
     int occ_smem[32] = { 0 };         // (0 = not queried yet) LDS size the cached occupancy below was queried for (per kernel variant)
     int occ_per_cu[32] = { 0 };
@@ -201,10 +202,13 @@ int check_params(const rt_camera* cam, const rt_params* p)
     return RT_OK;
 }
 
+// the sphere test's worst rounding error per squared distance (19 * 2^-24 = 1.13e-6: rt_bvh.h closest_hit_bvh), rounded up
+constexpr float kSphereTestError = 1.2e-6f;
 BvhRef bvh_ref(const rt_scene* sc)
 {
     BvhRef b;
     b.nodes = sc->d_nodes; b.pdata_off = sc->pdata_off; b.nnodes = sc->nnodes;
+    b.cone_k = sc->cone_k; b.rmin = sc->tree_rmin; b.rmax = sc->tree_rmax; b.reach = sc->tree_reach;
     return b;
 }
 
@@ -600,6 +604,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (!sc) return fail(RT_E_INVALID, "out of host memory");
     sc->device = device; sc->n = n; sc->use_bvh = use_bvh;
     std::vector<ShadeRec> h_shade((size_t)n);
+    float tree_rmax = 0.0f, tree_rmin = 0.0f; bool tree_spheres = false;
     for (int64_t i = 0; i < n; i++) {
         const rt_surface& s = surfaces[i];
         if (s.kind < 0 || s.kind > 3) { delete sc; return fail(RT_E_INVALID, "surface %lld: bad kind %d", (long long)i, s.kind); }
@@ -619,6 +624,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             if (use_bvh && !loose_spheres) {
                 BuildPrim bp;
                 const float r = std::fabs(s.g[3]);
+                tree_rmax = std::max(tree_rmax, r); tree_rmin = tree_spheres ? std::min(tree_rmin, r) : r; tree_spheres = true;
                 for (int k = 0; k < 3; k++) { bp.lo[k] = s.g[k] - r; bp.hi[k] = s.g[k] + r; bp.c[k] = s.g[k]; }
                 bp.ref = (uint32_t)src_pdata.size(); bp.surf = (uint32_t)i;
                 src_pdata.push_back(make_float4(g.a[0], g.a[1], g.a[2], g.a[3]));
@@ -692,6 +698,16 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             delete sc; return fail(RT_E_UNSUPPORTED, "BVH of %zu primitives is too large", bprims.size());
         }
         sc->nnodes = (int)(hb.nodes.size() / 8); sc->bvh_depth = hb.depth; sc->nprims = (int64_t)bprims.size();
+        if (tree_spheres) {
+            sc->cone_k = kSphereTestError; sc->tree_rmin = tree_rmin; sc->tree_rmax = tree_rmax;
+            float reach = 0.0f;
+            for (int k = 0; k < 3; k++) {
+                float m = 0.0f;
+                for (const BuildPrim& bp : bprims) m = std::max(m, std::max(std::fabs(bp.lo[k]), std::fabs(bp.hi[k])));
+                reach += m;
+            }
+            sc->tree_reach = reach;
+        }
     }
 
     hipError_t e = hipSetDevice(device);

@@ -144,6 +144,49 @@ def test_find_closest_one_million_spheres():
     assert (idx >= 0).mean() > 0.9 and (m["geom"][idx[idx >= 0]] == abi.GEOM_SPHERE).mean() > 0.3
 
 
+def _rays_into_the_fuzz_shell(m, n, seed, flat_axis=False):
+    """Rays from 300-1200 units away aimed at the rim of a sphere, into the shell between the sphere and where the
+    reference's f32 test still reports a hit (d = b^2 - C is off by up to ~1.2e-6 |O - centre|^2: Sphere.fs:18-27), at a
+    point of the rim where the sphere touches a face of its bounding box.  flat_axis: one direction component is
+    exactly zero or tiny (the traversal's widened ray never leaves the far plane of that axis)."""
+    rng = np.random.default_rng(seed)
+    nsph = int((m["geom"] == abi.GEOM_SPHERE).sum())
+    pick = rng.integers(0, nsph, n)
+    c = m["g"][pick, :3].astype(np.float64)
+    r = m["g"][pick, 3].astype(np.float64)
+    v = rng.normal(size=(n, 3))
+    v[:, 1] = np.abs(v[:, 1]) * 0.05 + 0.02
+    if flat_axis:
+        k = rng.choice([0, 2], n)
+        v[np.arange(n), k] = rng.choice([0.0, 1e-7, -3e-5, 2e-4, -9e-4], n)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    dist = rng.uniform(300.0, 1200.0, (n, 1))
+    o = (c + v * dist).astype(np.float32)
+    ax = np.eye(3)[rng.integers(0, 3, n)] * rng.choice([-1.0, 1.0], (n, 1))
+    u = ax - v * (ax * v).sum(axis=1, keepdims=True)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    fuzz = np.sqrt(r * r + 1.2e-6 * dist[:, 0] ** 2) - r
+    target = c + u * (r + fuzz * rng.uniform(-0.3, 1.0, n))[:, None]
+    d = target - o.astype(np.float64)
+    return o, (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("nspheres,nrays,flat", [(20000, 20000, False), (200000, 4000, False), (20000, 12000, True)])
+def test_find_closest_far_grazing_spheres(nspheres, nrays, flat):
+    """The linear scan's sphere test is fuzzy far from the origin of the ray: 500 units away it accepts a sphere of
+    radius 0.2 out to 0.58 from its centre, and reports the hit in front of the real sphere.  The tree must offer every
+    such sphere to the test (rt_bvh.h: the ray is walked as a cone).  With exact boxes 29 of the first case's 20 000
+    rays and 9 of the second case's 4 000 came back different from the scan (profiles/r03_experiments.txt section 11)."""
+    m = scenes.many_spheres(nspheres)
+    o, d = _rays_into_the_fuzz_shell(m, nrays, 5, flat)
+    s = Scene(surfaces=m)
+    t, idx = s.findClosestIntersection(o, d)
+    rt, ridx = O.find_closest(m, o, d)
+    assert (m["geom"][ridx[ridx >= 0]] == abi.GEOM_SPHERE).sum() > nrays // 4
+    bad = np.nonzero((idx != ridx) | (t != rt))[0]
+    assert len(bad) == 0, (len(bad), idx[bad[:5]], ridx[bad[:5]], t[bad[:5]], rt[bad[:5]])
+
+
 def test_c3_mesh_frame_properties():
     """config 3 at full size (100k triangles, 800x640): primary visibility equals the batch closest-hit query,
     the frame is finite, deterministic and independent of the column partition."""
