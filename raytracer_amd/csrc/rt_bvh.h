@@ -30,6 +30,9 @@ struct BvhRef {
     // per squared distance (0: no spheres), rmin / rmax = smallest / largest radius, reach = sum over the axes of the
     // largest |coordinate| of the root box (|c - O| <= reach + |O|_1 for every centre c)
     float cone_k, rmin, rmax, reach;
+    // triangles in the tree: their test is off by what a shift of the ray by up to ~lin_s |O - v0| would do; the boxes'
+    // own padding covers that for rays that cannot get further than lin_far from a primitive (FLT_MAX: no triangles)
+    float lin_s, lin_far;
 };
 
 constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a leaf ref)
@@ -218,7 +221,8 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     // inside the host's padding) all of this IS the plain slab test.
     // reciprocals for the slab test only (not on the exact path): v_rcp_f32 is enough
     f3 inv_n, inv_f, noi_lo, noi_hi;
-    if (bvh.cone_k == 0.0f) {
+    const float far = bvh.reach + (fabsf(O.x) + fabsf(O.y) + fabsf(O.z));       // no primitive is further from O than this
+    if (bvh.cone_k == 0.0f && __ballot(far > bvh.lin_far) == 0ull) {
         // the plain slab test: one reciprocal per axis (a zero component gives infinities and NaNs, which max / min ignore)
         inv_n = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
         inv_f = inv_n;
@@ -226,10 +230,11 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         noi_lo = F3(noi.x - 1e-6f * fabsf(noi.x), noi.y - 1e-6f * fabsf(noi.y), noi.z - 1e-6f * fabsf(noi.z));
         noi_hi = F3(noi.x + 1e-6f * fabsf(noi.x), noi.y + 1e-6f * fabsf(noi.y), noi.z + 1e-6f * fabsf(noi.z));
     } else {
-        const float tcap = fminf(tmin, (bvh.reach + (fabsf(O.x) + fabsf(O.y) + fabsf(O.z))) * 1.001f + 4.0f * bvh.rmax);
+        const float tcap = fminf(tmin, far * 1.001f + 4.0f * bvh.rmax);
         const float lc = tcap * 1.01f + 4.0f * bvh.rmax + 1e-20f;
         const float e = bvh.cone_k * lc * lc;
-        const float cs = 1.02f * e * __builtin_amdgcn_rcpf((__builtin_sqrtf(bvh.rmin * bvh.rmin + e) + bvh.rmin) * lc);
+        float cs = (far > bvh.lin_far) ? bvh.lin_s : 0.0f;
+        if (bvh.cone_k != 0.0f) cs = fmaxf(cs, 1.02f * e * __builtin_amdgcn_rcpf((__builtin_sqrtf(bvh.rmin * bvh.rmin + e) + bvh.rmin) * lc));
         const float ct = cs * 2.5f * __builtin_sqrtf(bvh.rmax * bvh.rmax + e);
         auto axis = [&](float o, float dk, float& in, float& jf, float& nlo, float& nhi) {
             const float ak = fabsf(dk);

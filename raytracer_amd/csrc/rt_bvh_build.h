@@ -23,6 +23,7 @@ struct HostBvh {
     std::vector<float4> nodes;      // 8 per node
     std::vector<float4> pdata;      // 3 per primitive slot, BVH order
     int depth = 0;                  // depth of the 4-wide tree
+    float pad = 0.0f;               // what every box was grown by (bvh_pad)
 };
 
 constexpr int kBvhLeaf = kBvhLeafMax;
@@ -157,6 +158,10 @@ inline int bvh_collapse(const std::vector<BinNode>& bin, int bn, int me, HostBvh
     return depth;
 }
 
+// what every box is grown by on every side: the primitives' own roundings at the scale of the scene (rt_bvh.h: what the
+// widened ray of a far origin takes over from)
+inline float bvh_pad(float scale) { return 2e-5f * (scale + 1.0f); }
+
 // prims: one entry per sphere / triangle with its exact bounds and its data in `src_pdata` (caller order).
 inline void bvh_build(std::vector<BuildPrim>& prims, const std::vector<float4>& src_pdata, HostBvh& out)
 {
@@ -165,7 +170,8 @@ inline void bvh_build(std::vector<BuildPrim>& prims, const std::vector<float4>& 
     float scale = 0.0f;
     for (const BuildPrim& p : prims)
         for (int k = 0; k < 3; k++) scale = std::max(scale, std::max(std::fabs(p.lo[k]), std::fabs(p.hi[k])));
-    const float pad = 1e-5f * (scale + 1.0f);
+    const float pad = bvh_pad(scale);
+    out.pad = pad;
     // SAH tree first; if it comes out too deep for the traversal stack (3 entries per level), the balanced
     // median tree, whose depth is known to fit, is built instead
     for (int attempt = 0; attempt < 2; attempt++) {

@@ -158,6 +158,7 @@ struct rt_scene {
     float4* d_nodes = nullptr;                 // the BVH: nodes, then the primitive records (one allocation, 32-bit offsets)
     uint32_t pdata_off = 0;                    // byte offset of the records
     int nnodes = 0, bvh_depth = 0;
+    float lin_s = 0.0f, lin_far = 3.402823466e38f;
     float cone_k = 0.0f, tree_rmin = 0.0f, tree_rmax = 0.0f, tree_reach = 0.0f;    // spheres in the tree: how the traversal widens the ray (rt_bvh.h closest_hit_bvh)
     int64_t nprims = 0;                        // primitives in the BVH
     int occ_smem[32] = { 0 };         // (0 = not queried yet) LDS size the cached occupancy below was queried for (per kernel variant)
@@ -204,11 +205,15 @@ int check_params(const rt_camera* cam, const rt_params* p)
 
 // the sphere test's worst rounding error per squared distance (19 * 2^-24 = 1.13e-6: rt_bvh.h closest_hit_bvh), rounded up
 constexpr float kSphereTestError = 1.2e-6f;
+// the triangle test answers as if the ray were shifted sideways by up to 2^-24 (4 + 3.5 / sin(angle between the ray and an
+// edge)) |O - v0| (rt_bvh.h): this slope covers every ray that makes more than 3 degrees with the edges
+constexpr float kTriangleConeSlope = 4e-6f;
 BvhRef bvh_ref(const rt_scene* sc)
 {
     BvhRef b;
     b.nodes = sc->d_nodes; b.pdata_off = sc->pdata_off; b.nnodes = sc->nnodes;
     b.cone_k = sc->cone_k; b.rmin = sc->tree_rmin; b.rmax = sc->tree_rmax; b.reach = sc->tree_reach;
+    b.lin_s = sc->lin_s; b.lin_far = sc->lin_far;
     return b;
 }
 
@@ -604,7 +609,7 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     if (!sc) return fail(RT_E_INVALID, "out of host memory");
     sc->device = device; sc->n = n; sc->use_bvh = use_bvh;
     std::vector<ShadeRec> h_shade((size_t)n);
-    float tree_rmax = 0.0f, tree_rmin = 0.0f; bool tree_spheres = false;
+    float tree_rmax = 0.0f, tree_rmin = 0.0f, tree_tri_rmax = 0.0f; bool tree_spheres = false;
     for (int64_t i = 0; i < n; i++) {
         const rt_surface& s = surfaces[i];
         if (s.kind < 0 || s.kind > 3) { delete sc; return fail(RT_E_INVALID, "surface %lld: bad kind %d", (long long)i, s.kind); }
@@ -644,6 +649,8 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
                 bp.lo[k] = std::min(a0, std::min(a1, a2)); bp.hi[k] = std::max(a0, std::max(a1, a2));
                 bp.c[k] = (bp.lo[k] + bp.hi[k]) * 0.5f;
             }
+            tree_tri_rmax = std::max(tree_tri_rmax, 0.5f * std::sqrt((bp.hi[0] - bp.lo[0]) * (bp.hi[0] - bp.lo[0]) + (bp.hi[1] - bp.lo[1]) * (bp.hi[1] - bp.lo[1]) +
+                                                                    (bp.hi[2] - bp.lo[2]) * (bp.hi[2] - bp.lo[2])));
             bp.ref = 0x80000000u | (uint32_t)src_pdata.size(); bp.surf = (uint32_t)i;
             src_pdata.push_back(make_float4(v0.x, v0.y, v0.z, e1.x));
             src_pdata.push_back(make_float4(e1.y, e1.z, e2.x, e2.y));
@@ -698,15 +705,14 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             delete sc; return fail(RT_E_UNSUPPORTED, "BVH of %zu primitives is too large", bprims.size());
         }
         sc->nnodes = (int)(hb.nodes.size() / 8); sc->bvh_depth = hb.depth; sc->nprims = (int64_t)bprims.size();
-        if (tree_spheres) {
-            sc->cone_k = kSphereTestError; sc->tree_rmin = tree_rmin; sc->tree_rmax = tree_rmax;
-            float reach = 0.0f;
-            for (int k = 0; k < 3; k++) {
-                float m = 0.0f;
-                for (const BuildPrim& bp : bprims) m = std::max(m, std::max(std::fabs(bp.lo[k]), std::fabs(bp.hi[k])));
-                reach += m;
-            }
-            sc->tree_reach = reach;
+        // how the traversal widens the ray (rt_bvh.h closest_hit_bvh)
+        if (tree_spheres) { sc->cone_k = kSphereTestError; sc->tree_rmin = tree_rmin; }
+        if (any_tri) { sc->lin_s = kTriangleConeSlope; sc->lin_far = hb.pad / kTriangleConeSlope; }
+        sc->tree_rmax = std::max(tree_rmax, tree_tri_rmax);
+        for (int k = 0; k < 3; k++) {
+            float m = 0.0f;
+            for (const BuildPrim& bp : bprims) m = std::max(m, std::max(std::fabs(bp.lo[k]), std::fabs(bp.hi[k])));
+            sc->tree_reach += m;
         }
     }
 

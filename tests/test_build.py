@@ -47,7 +47,7 @@ def test_no_kernel_spills_vector_registers_to_scratch():
     assert len(trace) == 48, sorted(kernels)          # {NODE64} x {linear, BVH ring 8, BVH ring 16} x {pass 0, 1, 2, 3} x {estimator}
     bodies = _kernel_bodies(os.path.join(csrc, "rt_hip.s"))
     for name, r in trace.items():
-        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] <= 32, (name, r)
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] <= 64, (name, r)
         touching = [l for l in bodies[name] if re.match(r"\s*(scratch_|buffer_)", l)]
         assert not touching, (name, touching[:4])
         targs = name.split("trace_kernelILb")[1]
