@@ -220,6 +220,12 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     // missed, the others never left on this axis.  With k = 0 (a tree of triangles: their test is off by ~1e-7 L,
     // inside the host's padding) all of this IS the plain slab test.
     // reciprocals for the slab test only (not on the exact path): v_rcp_f32 is enough
+    // A ray with a NaN or an infinity in it hits nothing in the scan (every comparison of its tests fails).  Here it would
+    // pass every slab test (max / min ignore NaNs), the empty child slots included — whose reference is 0, the root — and
+    // never come back: it does not enter the tree.
+    if (!(__builtin_isfinite(O.x) & __builtin_isfinite(O.y) & __builtin_isfinite(O.z) & __builtin_isfinite(D.x) & __builtin_isfinite(D.y) & __builtin_isfinite(D.z))) {
+        cur = kBvhDone; sp = 0; lo = 0;
+    }
     f3 inv_n, inv_f, noi_lo, noi_hi;
     const float far = bvh.reach + (fabsf(O.x) + fabsf(O.y) + fabsf(O.z));       // no primitive is further from O than this
     if (bvh.cone_k == 0.0f && __ballot(far > bvh.lin_far) == 0ull) {

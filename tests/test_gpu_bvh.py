@@ -182,11 +182,11 @@ def test_find_closest_unit_scale_mesh_edges_from_far_above():
     assert len(bad) == 0, (len(bad), idx[bad[:5]], ridx[bad[:5]], t[bad[:5]], rt[bad[:5]])
 
 
-def _rays_into_the_fuzz_shell(m, n, seed, flat_axis=False):
+def _rays_into_the_fuzz_shell(m, n, seed, flat_axis=0):
     """Rays from 300-1200 units away aimed at the rim of a sphere, into the shell between the sphere and where the
     reference's f32 test still reports a hit (d = b^2 - C is off by up to ~1.2e-6 |O - centre|^2: Sphere.fs:18-27), at a
-    point of the rim where the sphere touches a face of its bounding box.  flat_axis: one direction component is
-    exactly zero or tiny (the traversal's widened ray never leaves the far plane of that axis)."""
+    point of the rim where the sphere touches a face of its bounding box.  flat_axis 1 / 2: one / two direction
+    components are zero or tiny (the traversal's widened ray never leaves the far plane of such an axis)."""
     rng = np.random.default_rng(seed)
     nsph = int((m["geom"] == abi.GEOM_SPHERE).sum())
     pick = rng.integers(0, nsph, n)
@@ -194,13 +194,17 @@ def _rays_into_the_fuzz_shell(m, n, seed, flat_axis=False):
     r = m["g"][pick, 3].astype(np.float64)
     v = rng.normal(size=(n, 3))
     v[:, 1] = np.abs(v[:, 1]) * 0.05 + 0.02
-    if flat_axis:
+    if flat_axis == 1:
         k = rng.choice([0, 2], n)
         v[np.arange(n), k] = rng.choice([0.0, 1e-7, -3e-5, 2e-4, -9e-4], n)
+    elif flat_axis == 2:                    # along an axis: two tiny components
+        k = rng.integers(0, 3, n)
+        v = rng.choice([0.0, 1e-8, -2e-5, 3e-4], (n, 3)) * rng.choice([-1.0, 1.0], (n, 3))
+        v[np.arange(n), k] = rng.choice([-1.0, 1.0], n)
     v /= np.linalg.norm(v, axis=1, keepdims=True)
     dist = rng.uniform(300.0, 1200.0, (n, 1))
     o = (c + v * dist).astype(np.float32)
-    ax = np.eye(3)[rng.integers(0, 3, n)] * rng.choice([-1.0, 1.0], (n, 1))
+    ax = np.eye(3)[(np.argmax(np.abs(v), axis=1) + rng.integers(1, 3, n)) % 3] * rng.choice([-1.0, 1.0], (n, 1))   # not the ray's main axis
     u = ax - v * (ax * v).sum(axis=1, keepdims=True)
     u /= np.linalg.norm(u, axis=1, keepdims=True)
     fuzz = np.sqrt(r * r + 1.2e-6 * dist[:, 0] ** 2) - r
@@ -209,7 +213,7 @@ def _rays_into_the_fuzz_shell(m, n, seed, flat_axis=False):
     return o, (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
 
 
-@pytest.mark.parametrize("nspheres,nrays,flat", [(20000, 20000, False), (200000, 4000, False), (20000, 12000, True)])
+@pytest.mark.parametrize("nspheres,nrays,flat", [(20000, 20000, 0), (200000, 4000, 0), (20000, 12000, 1), (20000, 12000, 2)])
 def test_find_closest_far_grazing_spheres(nspheres, nrays, flat):
     """The linear scan's sphere test is fuzzy far from the origin of the ray: 500 units away it accepts a sphere of
     radius 0.2 out to 0.58 from its centre, and reports the hit in front of the real sphere.  The tree must offer every
@@ -220,9 +224,32 @@ def test_find_closest_far_grazing_spheres(nspheres, nrays, flat):
     s = Scene(surfaces=m)
     t, idx = s.findClosestIntersection(o, d)
     rt, ridx = O.find_closest(m, o, d)
-    assert (m["geom"][ridx[ridx >= 0]] == abi.GEOM_SPHERE).sum() > nrays // 4
+    assert (m["geom"][ridx[ridx >= 0]] == abi.GEOM_SPHERE).sum() > nrays // 5
     bad = np.nonzero((idx != ridx) | (t != rt))[0]
     assert len(bad) == 0, (len(bad), idx[bad[:5]], ridx[bad[:5]], t[bad[:5]], rt[bad[:5]])
+
+
+@pytest.mark.timeout(60)
+def test_find_closest_rays_that_are_not_numbers():
+    """A NaN or an infinity in a ray: the scan's tests all fail (no hit).  In the tree such a ray passes every slab test,
+    the empty child slots (reference 0 = the root) included: before the guard in closest_hit_bvh it never came back."""
+    m = np.concatenate([_dense_spheres(3000, 5), scenes.heightfield_mesh(16, environment=False)])
+    rng = np.random.default_rng(2)
+    n = 4096
+    o = rng.uniform(-10, 10, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    which = rng.integers(0, 4, n)
+    comp = rng.integers(0, 3, n)
+    o[which == 1, comp[which == 1]] = np.nan
+    d[which == 2, comp[which == 2]] = np.nan
+    d[which == 3, comp[which == 3]] = np.inf
+    o[::97, 0] = -np.inf
+    s = Scene(surfaces=m)
+    t, idx = s.findClosestIntersection(o, d)
+    rt, ridx = O.find_closest(m, o, d)
+    assert np.array_equal(idx, ridx) and np.array_equal(t, rt)
+    assert (ridx[which == 0] >= 0).mean() > 0.5 and np.all(ridx[(which == 2)] == -1)
 
 
 def test_c3_mesh_frame_properties():
