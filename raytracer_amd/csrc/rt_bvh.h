@@ -222,12 +222,10 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     // reciprocals for the slab test only (not on the exact path): v_rcp_f32 is enough
     // A ray with a NaN or an infinity in it hits nothing in the scan (every comparison of its tests fails).  Here it would
     // pass every slab test (max / min ignore NaNs), the empty child slots included — whose reference is 0, the root — and
-    // never come back: it does not enter the tree.
-    if (!(__builtin_isfinite(O.x) & __builtin_isfinite(O.y) & __builtin_isfinite(O.z) & __builtin_isfinite(D.x) & __builtin_isfinite(D.y) & __builtin_isfinite(D.z))) {
-        cur = kBvhDone; sp = 0; lo = 0;
-    }
+    // never come back: it does not enter the tree (nor does a ray whose coordinates add up beyond FLT_MAX).
     f3 inv_n, inv_f, noi_lo, noi_hi;
     const float far = bvh.reach + (fabsf(O.x) + fabsf(O.y) + fabsf(O.z));       // no primitive is further from O than this
+    if (!(far + (fabsf(D.x) + fabsf(D.y) + fabsf(D.z)) < kFltMax)) { cur = kBvhDone; sp = 0; lo = 0; }      // (false for a NaN, too)
     if (bvh.cone_k == 0.0f && __ballot(far > bvh.lin_far) == 0ull) {
         // the plain slab test: one reciprocal per axis (a zero component gives infinities and NaNs, which max / min ignore)
         inv_n = F3(__builtin_amdgcn_rcpf(D.x), __builtin_amdgcn_rcpf(D.y), __builtin_amdgcn_rcpf(D.z));
