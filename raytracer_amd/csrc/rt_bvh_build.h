@@ -120,20 +120,72 @@ inline float bvh_area(const BinNode& n)
     return dx * dy + dy * dz + dz * dx;
 }
 
+// Which binary nodes become 4-wide nodes.  Greedy (round 1-2): a node adopts grandchildren, largest area first, until it
+// has four children — which fills the upper node and leaves its children half empty (16 primitives split 8|8, 4|4 ...:
+// the root adopts four grandchildren of two leaves each, five nodes where three would do; measured on the 1M-sphere
+// tree: 2.95 children per node).  Now: the collapse that minimises the summed area of the wide nodes (= the expected
+// number of node visits of a random ray), by dynamic programming over the binary tree (Ylitie, Karras, Laine 2017,
+// section 3.1): cost[n][i] = least cost of the subtree of n when it may occupy up to i child slots of the node above.
+#ifndef RT_BVH_DP_COLLAPSE
+#define RT_BVH_DP_COLLAPSE 1
+#endif
+struct CollapsePlan {
+    std::vector<float> cost;            // [4 * n + i - 1]
+    std::vector<unsigned char> take;    // [4 * n + i - 1]: slots really used for (n, i); 1 = n is a child (a leaf, or a node of its own)
+    std::vector<unsigned char> left;    // [4 * n + j - 1]: of j slots passed through n, how many go to its left child
+};
+inline void bvh_plan_collapse(const std::vector<BinNode>& bin, CollapsePlan& pl)
+{
+    const size_t nb = bin.size();
+    pl.cost.assign(4 * nb, 0.0f); pl.take.assign(4 * nb, 1); pl.left.assign(4 * nb, 0);
+    // children are created after their parent (bvh_bin_build): a reverse sweep sees every child before its parent
+    for (size_t n = nb; n-- > 0;) {
+        const BinNode& b = bin[n];
+        if (b.count > 0) continue;                                  // a leaf costs the same wherever it hangs: 0 here
+        const float* cl = &pl.cost[4 * (size_t)b.left]; const float* cr = &pl.cost[4 * (size_t)b.right];
+        float dist[5]; int dk[5];
+        for (int j = 2; j <= 4; j++) {
+            dist[j] = INFINITY; dk[j] = 1;
+            for (int k = 1; k < j; k++) { const float c = cl[k - 1] + cr[j - k - 1]; if (c < dist[j]) { dist[j] = c; dk[j] = k; } }
+            pl.left[4 * n + j - 1] = (unsigned char)dk[j];
+        }
+        pl.cost[4 * n] = bvh_area(b) + dist[4]; pl.take[4 * n] = 1;           // one slot: a node of its own with four slots to fill
+        for (int i = 2; i <= 4; i++) {
+            if (dist[i] < pl.cost[4 * n + i - 2]) { pl.cost[4 * n + i - 1] = dist[i]; pl.take[4 * n + i - 1] = (unsigned char)i; }
+            else { pl.cost[4 * n + i - 1] = pl.cost[4 * n + i - 2]; pl.take[4 * n + i - 1] = pl.take[4 * n + i - 2]; }
+        }
+    }
+}
+// the children of the wide node made from binary node x, which may use `slots` slots
+inline void bvh_gather(const std::vector<BinNode>& bin, const CollapsePlan& pl, int x, int slots, int* kids, int& nk)
+{
+    const int j = bin[x].count > 0 ? 1 : pl.take[4 * (size_t)x + slots - 1];
+    if (j == 1) { kids[nk++] = x; return; }
+    const int kl = pl.left[4 * (size_t)x + j - 1];
+    bvh_gather(bin, pl, bin[x].left, kl, kids, nk);
+    bvh_gather(bin, pl, bin[x].right, j - kl, kids, nk);
+}
+
 // emits the 4-wide node for binary node `bn` at index `me` (already reserved); returns the subtree depth
-inline int bvh_collapse(const std::vector<BinNode>& bin, int bn, int me, HostBvh& out)
+inline int bvh_collapse(const std::vector<BinNode>& bin, const CollapsePlan& pl, int bn, int me, HostBvh& out)
 {
     int kids[4]; int nk = 0;
     if (bin[bn].count > 0) kids[nk++] = bn;                 // a leaf root: one leaf child
-    else { kids[nk++] = bin[bn].left; kids[nk++] = bin[bn].right; }
-    while (nk < 4) {
-        int best = -1; float ba = -1.0f;
-        for (int i = 0; i < nk; i++)
-            if (bin[kids[i]].count == 0 && bvh_area(bin[kids[i]]) > ba) { ba = bvh_area(bin[kids[i]]); best = i; }
-        if (best < 0) break;
-        const int k = kids[best];
-        kids[best] = bin[k].left;
-        kids[nk++] = bin[k].right;
+    else if (RT_BVH_DP_COLLAPSE) {
+        const int kl = pl.left[4 * (size_t)bn + 3];
+        bvh_gather(bin, pl, bin[bn].left, kl, kids, nk);
+        bvh_gather(bin, pl, bin[bn].right, 4 - kl, kids, nk);
+    } else {
+        kids[nk++] = bin[bn].left; kids[nk++] = bin[bn].right;
+        while (nk < 4) {
+            int best = -1; float ba = -1.0f;
+            for (int i = 0; i < nk; i++)
+                if (bin[kids[i]].count == 0 && bvh_area(bin[kids[i]]) > ba) { ba = bvh_area(bin[kids[i]]); best = i; }
+            if (best < 0) break;
+            const int k = kids[best];
+            kids[best] = bin[k].left;
+            kids[nk++] = bin[k].right;
+        }
     }
     float f[32]; memset(f, 0, sizeof f);
     uint32_t refs[4] = { 0, 0, 0, 0 };
@@ -154,7 +206,7 @@ inline int bvh_collapse(const std::vector<BinNode>& bin, int bn, int me, HostBvh
     memcpy(&out.nodes[(size_t)me * 8], f, sizeof f);
     int depth = 1;
     for (int i = 0; i < nk; i++)
-        if (child_node[i] >= 0) depth = std::max(depth, 1 + bvh_collapse(bin, kids[i], child_node[i], out));
+        if (child_node[i] >= 0) depth = std::max(depth, 1 + bvh_collapse(bin, pl, kids[i], child_node[i], out));
     return depth;
 }
 
@@ -186,7 +238,9 @@ inline void bvh_build(std::vector<BuildPrim>& prims, const std::vector<float4>& 
         out.nodes.clear();
         out.nodes.reserve(prims.size() * 4);
         out.nodes.resize(8);
-        out.depth = bvh_collapse(bin, 0, 0, out);
+        CollapsePlan pl;
+        if (RT_BVH_DP_COLLAPSE) bvh_plan_collapse(bin, pl);
+        out.depth = bvh_collapse(bin, pl, 0, 0, out);
         if (3 * out.depth + 1 <= kBvhStack) break;
     }
     out.pdata.resize(3 * prims.size());
