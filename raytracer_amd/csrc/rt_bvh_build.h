@@ -1,7 +1,7 @@
 // rt_bvh_build.h — host-side BVH construction for large scenes (spheres and triangles; planes stay in the
 // linear list).  Not in the reference (Geometry/AABB.fs is empty).  A binary tree is built with binned
 // surface-area-heuristic splits (object-median splits as the fallback), then collapsed into 4-wide nodes
-// (rt_bvh.h): a node adopts its grandchildren, largest area first, until it has four children.
+// (rt_bvh.h): the collapse with the least summed node area (bvh_plan_collapse).
 #pragma once
 #include "rt_bvh.h"
 
