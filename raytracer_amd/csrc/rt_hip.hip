@@ -602,6 +602,12 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
     // (a scene of many planes and nothing else has no primitive to put in a tree: it is scanned)
     const bool use_bvh = (any_tri || n > kBvhThreshold) && nprim > 0;
     std::vector<BuildPrim> bprims;
+    // A sphere or triangle with a NaN or an infinity in it is never hit by the scan (every comparison of its test fails, or
+    // gives t = inf): it stays out of the tree, whose builder and boxes need numbers (its tree_rmax / rmin share included).
+    auto finite_box = [](const BuildPrim& bp) {
+        for (int k = 0; k < 3; k++) if (!std::isfinite(bp.lo[k]) || !std::isfinite(bp.hi[k])) return false;
+        return true;
+    };
     HostBvh hb;
     std::vector<float4> src_pdata;
     if (use_bvh) bprims.reserve((size_t)nprim);
@@ -629,11 +635,13 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
             if (use_bvh && !loose_spheres) {
                 BuildPrim bp;
                 const float r = std::fabs(s.g[3]);
-                tree_rmax = std::max(tree_rmax, r); tree_rmin = tree_spheres ? std::min(tree_rmin, r) : r; tree_spheres = true;
                 for (int k = 0; k < 3; k++) { bp.lo[k] = s.g[k] - r; bp.hi[k] = s.g[k] + r; bp.c[k] = s.g[k]; }
                 bp.ref = (uint32_t)src_pdata.size(); bp.surf = (uint32_t)i;
                 src_pdata.push_back(make_float4(g.a[0], g.a[1], g.a[2], g.a[3]));
-                bprims.push_back(bp);
+                if (finite_box(bp)) {
+                    tree_rmax = std::max(tree_rmax, r); tree_rmin = tree_spheres ? std::min(tree_rmin, r) : r; tree_spheres = true;
+                    bprims.push_back(bp);
+                }
             }
         } else if (s.geom == RT_GEOM_TRIANGLE) {
             // the build's own Hitable (no reference counterpart): v0, e1 = v1 - v0, e2 = v2 - v0, constant
@@ -649,13 +657,15 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
                 bp.lo[k] = std::min(a0, std::min(a1, a2)); bp.hi[k] = std::max(a0, std::max(a1, a2));
                 bp.c[k] = (bp.lo[k] + bp.hi[k]) * 0.5f;
             }
-            tree_tri_rmax = std::max(tree_tri_rmax, 0.5f * std::sqrt((bp.hi[0] - bp.lo[0]) * (bp.hi[0] - bp.lo[0]) + (bp.hi[1] - bp.lo[1]) * (bp.hi[1] - bp.lo[1]) +
-                                                                    (bp.hi[2] - bp.lo[2]) * (bp.hi[2] - bp.lo[2])));
             bp.ref = 0x80000000u | (uint32_t)src_pdata.size(); bp.surf = (uint32_t)i;
             src_pdata.push_back(make_float4(v0.x, v0.y, v0.z, e1.x));
             src_pdata.push_back(make_float4(e1.y, e1.z, e2.x, e2.y));
             src_pdata.push_back(make_float4(e2.z, 0.0f, 0.0f, 0.0f));
-            bprims.push_back(bp);
+            if (finite_box(bp)) {
+                tree_tri_rmax = std::max(tree_tri_rmax, 0.5f * std::sqrt((bp.hi[0] - bp.lo[0]) * (bp.hi[0] - bp.lo[0]) + (bp.hi[1] - bp.lo[1]) * (bp.hi[1] - bp.lo[1]) +
+                                                                        (bp.hi[2] - bp.lo[2]) * (bp.hi[2] - bp.lo[2])));
+                bprims.push_back(bp);
+            }
         } else if (s.geom == RT_GEOM_PLANE) {
             const H3 nraw = { s.g[0], s.g[1], s.g[2] };
             const float d = s.g[3];

@@ -50,6 +50,16 @@ def test_many_spheres_branching():
                    seed=2, cameraOriginWS=(0.0, 6.0, 12.0), lookAt=(0.0, -4.0, -20.0)))
 
 
+def test_sparse_far_sphere_field_frame_matches_the_scan():
+    """config 5's scene at its own scale (a field 1000 units across, radii 0.2-1) with 40 000 spheres, so that the
+    brute-force oracle can render the frame: image, depth, object IDs and the ray count.  Primaries and bounces travel
+    hundreds of units here, where the scan's sphere test is fuzzy (rt_bvh.h: the ray as a cone); the dense small fields of
+    the other frame tests never leave the range that exact boxes cover."""
+    m = scenes.many_spheres(40_000)
+    _compare(Scene(surfaces=m, width=256, height=144, samplesPerPixel=2, maxTraceDepth=8, jitter=1, seed=3, lambertian_samples=1,
+                   **scenes.MANY_SPHERES_CAMERA), nthreads=16)
+
+
 def test_ties_resolve_to_lowest_index():
     """Surface.fs:53 strict '<': of coincident surfaces the first in array order wins, also through the BVH."""
     m = scenes.heightfield_mesh(8, environment=False)
@@ -250,6 +260,30 @@ def test_find_closest_rays_that_are_not_numbers():
     rt, ridx = O.find_closest(m, o, d)
     assert np.array_equal(idx, ridx) and np.array_equal(t, rt)
     assert (ridx[which == 0] >= 0).mean() > 0.5 and np.all(ridx[(which == 2)] == -1)
+
+
+def test_primitives_that_are_not_numbers_stay_out_of_the_tree():
+    """A sphere or triangle with a NaN or an infinity in it is never hit by the scan; the tree's builder must neither choke
+    on it nor box it (the scene is created, and every ray gets the scan's answer)."""
+    m = np.concatenate([_dense_spheres(1500, 9), scenes.heightfield_mesh(12, environment=False)])
+    sph = np.flatnonzero(m["geom"] == abi.GEOM_SPHERE)
+    tri = np.flatnonzero(m["geom"] == abi.GEOM_TRIANGLE)
+    m["g"][sph[3], 0] = np.nan
+    m["g"][sph[40], 3] = np.inf
+    m["g"][sph[77], 1] = -np.inf
+    m["g"][sph[100], 3] = np.nan
+    m["g"][tri[5], 4] = np.nan
+    m["g"][tri[9], 6] = np.inf
+    rng = np.random.default_rng(4)
+    n = 20000
+    o = rng.uniform(-15, 15, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    s = Scene(surfaces=m)
+    t, idx = s.findClosestIntersection(o, d)
+    rt, ridx = O.find_closest(m, o, d)
+    assert np.array_equal(idx, ridx) and np.array_equal(t, rt)
+    assert not np.isin(idx, [sph[3], sph[40], sph[77], sph[100], tri[5], tri[9]]).any() and (idx >= 0).mean() > 0.5
 
 
 def test_c3_mesh_frame_properties():
