@@ -1,5 +1,5 @@
 """Seeded random scenes and parameter combinations against the oracle: sphere counts on both sides of the BVH threshold
-(with and without a small mesh), every estimator / pass / ring / sample-count / depth / background combination the draw
+(with and without a small mesh; a cluster in front of the reference camera, or a sparse field a kilometre across), every estimator / pass / ring / sample-count / depth / background combination the draw
 produces, odd frame sizes, and a random column partition.  Bit-exact object IDs, depth, hit mask and ray count, RGB
 within 1e-4 (tests/test_gpu_parity.py::_compare)."""
 import os
@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _random_scene(rng):
+    if rng.random() < 0.25:
+        # config 5's kilometre-wide sparse field seen from config 5's camera: rays travel hundreds of units, where the
+        # scan's sphere test is fuzzy and the tree walks the ray as a cone (rt_bvh.h)
+        return scenes.many_spheres(int(rng.choice([70, 300, 2000, 9000])), seed=int(rng.integers(1 << 30))), dict(scenes.MANY_SPHERES_CAMERA)
     n = int(rng.choice([3, 12, 40, 70, 300]))
     s = scenes.many_spheres(n, seed=int(rng.integers(1 << 30)), environment=False)
     # a cluster in front of the reference camera instead of the kilometre-wide field
@@ -29,7 +33,7 @@ def _random_scene(rng):
     if rng.random() < 0.4:
         parts.insert(0, scenes.heightfield_mesh(int(rng.choice([6, 14])), seed=int(rng.integers(1000)), environment=False,
                                                 base=-5.9, amplitude=float(rng.uniform(0.3, 1.5))))
-    return np.concatenate(parts)
+    return np.concatenate(parts), {}
 
 
 # RT_FUZZ_CASES / RT_FUZZ_BASE in the environment widen the draw for a one-off soak (the committed default stays small)
@@ -40,7 +44,7 @@ _BASE = int(os.environ.get("RT_FUZZ_BASE", "1000"))
 @pytest.mark.parametrize("case", range(_CASES))
 def test_random_scene_and_parameters(case):
     rng = np.random.default_rng(_BASE + case)
-    surfaces = _random_scene(rng)
+    surfaces, camera = _random_scene(rng)
     estimator = int(rng.random() < 0.35)
     depth = int(rng.choice([0, 1, 2, 3, 4, 5, 14])) if estimator or rng.random() < 0.5 else int(rng.choice([0, 1, 2, 3, 4]))
     spp = int(rng.choice([1, 2, 3, 9, 16]))
@@ -54,7 +58,7 @@ def test_random_scene_and_parameters(case):
     sc = Scene(surfaces=surfaces, width=w, height=h, samplesPerPixel=spp, maxTraceDepth=depth, jitter=int(rng.random() < 0.7),
                seed=int(rng.integers(1, 1 << 40)), lambertian_samples=lamb, backgroundColor=bg, estimator=estimator,
                two_pass=int(rng.random() < 0.3), bvh_ring=int(rng.choice([0, 0, 16])),
-               bvh_min_active=int(rng.choice([0, 0, 7, 40])), pool_blocks=int(rng.choice([0, 0, 3])))
+               bvh_min_active=int(rng.choice([0, 0, 7, 40])), pool_blocks=int(rng.choice([0, 0, 3])), **camera)
     _compare(sc)
     # a random interleaved column share renders exactly its columns of that frame
     n = int(rng.integers(2, 5)); r = int(rng.integers(0, n))
