@@ -33,11 +33,18 @@ def _random_scene(rng):
     if rng.random() < 0.4:
         parts.insert(0, scenes.heightfield_mesh(int(rng.choice([6, 14])), seed=int(rng.integers(1000)), environment=False,
                                                 base=-5.9, amplitude=float(rng.uniform(0.3, 1.5))))
-    return np.concatenate(parts), {}
+    camera = {}
+    if rng.random() < 0.2:
+        # the same cluster through a long lens from 20 or 60 times as far: primaries start hundreds of units from every
+        # primitive (the widened ray for spheres AND triangles), their bounces right next to them, in the same waves
+        k = float(rng.choice([20.0, 60.0]))
+        o, la = np.array([-3.0, 6.0, 15.0]), np.array([-1.0, 1.0, -10.0])
+        camera = dict(cameraOriginWS=tuple(la + (o - la) * k), lookAt=tuple(la), fov=2.0 * np.arctan(np.tan(np.pi / 8.0) / k))
+    return np.concatenate(parts), camera
 
 
 # RT_FUZZ_CASES / RT_FUZZ_BASE in the environment widen the draw for a one-off soak (the committed default stays small)
-_CASES = int(os.environ.get("RT_FUZZ_CASES", "14"))
+_CASES = int(os.environ.get("RT_FUZZ_CASES", "40"))
 _BASE = int(os.environ.get("RT_FUZZ_BASE", "1000"))
 
 
