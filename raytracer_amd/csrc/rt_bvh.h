@@ -66,6 +66,17 @@ RT_DEV bool better_hit(bool ok, float t, int idx, float tmin, int best)
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+// Round 3, last session: the 8-entry stack ring addressed as raw LDS bytes (RT_BVH_RING2, closest_hit_bvh below).
+#ifndef RT_BVH_RING2
+#define RT_BVH_RING2 1        // 0: A/B build, the ring through generic pointers and a dump word
+#endif
+#ifndef RT_BVH_FOLD_SHRINK
+#define RT_BVH_FOLD_SHRINK 1  // 0: A/B build, the entry parameter of every box is shrunk by a multiply of its own
+#endif
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+RT_DEV uint32_t lds_addr_of(uint32_t* p) { return (uint32_t)(uintptr_t)(lds_u32*)p; }
+RT_DEV void lds_store(uint32_t a, uint32_t v) { *(lds_u32*)(uintptr_t)a = v; }
+RT_DEV uint32_t lds_load(uint32_t a) { return *(lds_u32*)(uintptr_t)a; }
 #ifndef RT_BVH_PACK_OFF
 #define RT_BVH_PACK_OFF 1     // 0: A/B build, six offset registers and seven selects per round
 #endif
@@ -125,10 +136,19 @@ RT_DEV void box_entry2(v2f nearx, v2f neary, v2f nearz, v2f farx, v2f fary, v2f 
         tna = fmaxf(fmaxf(x0.x, y0.x), fmaxf(z0.x, 0.0f)); tfa = fminf(fminf(x1.x, y1.x), fminf(z1.x, tmax));
         tnb = fmaxf(fmaxf(x0.y, y0.y), fmaxf(z0.y, 0.0f)); tfb = fminf(fminf(x1.y, y1.y), fminf(z1.y, tmax));
     }
-    // the |t| share of the rounding error, both sides at once
-    ta = (tna * 0.999998f <= tfa) ? tna : kFltMax;
-    tb = (tnb * 0.999998f <= tfb) ? tnb : kFltMax;
+    // the |t| share of the rounding error, both sides at once: the entry shrunk by 2e-6 relative before it is compared
+    // with the exit.  RT_BVH_FOLD_SHRINK: the exit is widened instead, once per ray — the far planes' reciprocals and
+    // addends and `tmax` arrive multiplied by kFarWiden = 1 + 2.5e-6 (tn (1 - 2e-6) <= X implies tn <= X (1 + 2.5e-6) for
+    // X >= 0, and for X < 0 both forms reject since tn >= 0) — so a box costs a compare and a select, no multiply.
+    if (RT_BVH_FOLD_SHRINK) {
+        ta = (tna <= tfa) ? tna : kFltMax;
+        tb = (tnb <= tfb) ? tnb : kFltMax;
+    } else {
+        ta = (tna * 0.999998f <= tfa) ? tna : kFltMax;
+        tb = (tnb * 0.999998f <= tfb) ? tnb : kFltMax;
+    }
 }
+constexpr float kFarWiden = RT_BVH_FOLD_SHRINK ? 1.0000025f : 1.0f;
 
 // a x b and a . b with explicit FMAs, in a fixed order (the CPU checker mirrors them with fmaf)
 RT_DEV f3 cross_fma(f3 a, f3 b)
@@ -263,6 +283,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         axis(O.y, D.y, inv_n.y, inv_f.y, noi_lo.y, noi_hi.y);
         axis(O.z, D.z, inv_n.z, inv_f.z, noi_lo.z, noi_hi.z);
     }
+    if (RT_BVH_FOLD_SHRINK) { inv_f = inv_f * kFarWiden; noi_hi = noi_hi * kFarWiden; }
     const v2f mx = { inv_n.x, inv_f.x }, my = { inv_n.y, inv_f.y }, mz = { inv_n.z, inv_f.z };
     const v2f cx = { noi_lo.x, noi_hi.x }, cy = { noi_lo.y, noi_hi.y }, cz = { noi_lo.z, noi_hi.z };
     const f3 inv = inv_n;
@@ -275,8 +296,21 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     const uint32_t in_off0 = onx | (ofx << 8) | (ony << 16), in_off1 = ofy | (onz << 8) | (ofz << 16) | (node_row(6) << 24);
     constexpr uint32_t kLeafOff0 = 0u | (16u << 8) | (32u << 16), kLeafOff1 = 0u | (16u << 8) | (32u << 16) | (32u << 24);
     const char* const node_bytes = reinterpret_cast<const char*>(bvh.nodes);
+    // RING2 (the 8-entry LDS ring of the render kernels): `sp` and `lo` count in BYTES of ring rows (256 per entry) and
+    // the ring is addressed as raw LDS bytes, l4 | (sp & 0x700) — one v_and_or_b32 per address where the generic form cost
+    // a shift, a mask and a three-operand add (the caller puts the ring where bits 8..10 of every lane's column base are
+    // zero: trace_kernel checks it).  The pop is a ds_read (the compiler had merged the LDS read and the rare read of the
+    // backing store into ONE flat load through a selected pointer: flat latency on the load -> decide -> load chain).
+    constexpr bool RING2 = RT_BVH_RING2 && SPILL && K <= 8;
+    const uint32_t l4 = RING2 ? lds_addr_of(stack) : 0u;
     auto pop = [&]() -> uint32_t {
         if (sp == 0) return kBvhDone;
+        if (RING2) {
+            sp -= 256;
+            uint32_t v = lds_load(l4 | ((uint32_t)sp & 0x700u));
+            if (sp < lo) { lo = sp; v = backing()[sp >> 2]; }
+            return v;
+        }
         sp--;
         uint32_t v = stack[(sp & (K - 1)) * stride];
         if (SPILL && sp < lo) { lo = sp; v = backing()[sp * 64]; }
@@ -338,24 +372,26 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     issue();
     while (true) {
         // what this round's inner lanes still have to push once the next loads are under way
-        const bool pushing = do_in;
+        bool pushing = do_in;
         uint32_t p0 = 0u, p1 = 0u, p2 = 0u; int nh = 0;
         if (do_in) {
             // ---- inner node: four slab tests
             const float4 nx4 = d[0], fx4 = d[1], ny4 = d[2], fy4 = d[3], nz4 = d[4], fz4 = d[5], rf = d[6];
             uint32_t r0 = __float_as_uint(rf.x), r1 = __float_as_uint(rf.y), r2 = __float_as_uint(rf.z), r3 = __float_as_uint(rf.w);
             float t0, t1, t2, t3;
+            const float tmaxw = tmin * kFarWiden;
             box_entry2(v2f{ nx4.x, nx4.y }, v2f{ ny4.x, ny4.y }, v2f{ nz4.x, nz4.y }, v2f{ fx4.x, fx4.y }, v2f{ fy4.x, fy4.y }, v2f{ fz4.x, fz4.y },
-                       mx, my, mz, cx, cy, cz, tmin, t0, t1);
+                       mx, my, mz, cx, cy, cz, tmaxw, t0, t1);
             box_entry2(v2f{ nx4.z, nx4.w }, v2f{ ny4.z, ny4.w }, v2f{ nz4.z, nz4.w }, v2f{ fx4.z, fx4.w }, v2f{ fy4.z, fy4.w }, v2f{ fz4.z, fz4.w },
-                       mx, my, mz, cx, cy, cz, tmin, t2, t3);
+                       mx, my, mz, cx, cy, cz, tmaxw, t2, t3);
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
             sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
             // the hits are a prefix of the sorted four: descend into the nearest, push the others far to near (below).
             // A lane pushes (it has a hit and descends) or pops (it has none), never both in one round.
             const bool h2 = t2 < kFltMax, h3 = t3 < kFltMax;
             nh = (t1 < kFltMax ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
-            p0 = h3 ? r3 : (h2 ? r2 : r1); p1 = h3 ? r2 : r1; p2 = r1;
+            if (RING2) { p0 = r3; p1 = r2; p2 = r1; pushing = nh != 0; nh <<= 8; }   // the sorted three as they are (below)
+            else { p0 = h3 ? r3 : (h2 ? r2 : r1); p1 = h3 ? r2 : r1; p2 = r1; }
             cur = (t0 < kFltMax) ? r0 : pop();
         }
         if (do_leaf) {
@@ -377,7 +413,22 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         if (more) issue();
         // ---- this round's pushes.  Branch-free: three entries are always stored, those beyond the new top are garbage in
         // free slots.
-        if (pushing) {
+        if (RING2) {
+            // Far to near from the old top: the farthest hit lands at sp, the nearest at the new top.  All three sorted
+            // references are stored, unconditionally and in this order — r3 at the old top, r2 one above it when there are
+            // three hits (else at the old top too), r1 at the new top: one wave's LDS operations complete in order, so with
+            // fewer than three hits the later, valid stores overwrite the earlier ones and nothing is written outside
+            // [sp, sp + nh).  (Before: three selects for the values, three for dump-or-ring addresses, nine address
+            // operations: 22 vector instructions per inner round, now 9.)
+            if (pushing) {
+                while (sp + nh - lo > K * 256) { backing()[lo >> 2] = lds_load(l4 | ((uint32_t)lo & 0x700u)); lo += 256; }
+                const int nsp = sp + nh;
+                lds_store(l4 | ((uint32_t)sp & 0x700u), p0);
+                lds_store(l4 | ((uint32_t)max(nsp - 512, sp) & 0x700u), p1);
+                lds_store(l4 | ((uint32_t)(nsp - 256) & 0x700u), p2);
+                sp = nsp;
+            }
+        } else if (pushing) {
             if (SPILL && K <= 8) {
                 // (a 16-entry ring has room to spare and its kernel no LDS to spare: it keeps the simpler rule below)
                 // room for exactly the nh entries pushed; the stores beyond the new top go to the lane's `dump` word (any

@@ -447,7 +447,7 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
     // 8 entries for every tree since the ring makes room for exactly the entries pushed (rt_bvh.h): the 1M-sphere tree,
     // which used to overflow the short ring into HBM (-11 %), now gains 10 % from the 15 instead of 12 waves per CU
     const int ring = p->bvh_ring ? p->bvh_ring : 8;
-    const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring)).pool + (size_t)nf * 64 * a.nblk + (sc->use_bvh ? 64 * ring : 0));
+    const size_t smem = sizeof(uint32_t) * ((size_t)LdsLayout(slots_of(sc->use_bvh, ring), sc->use_bvh ? ring : 0).pool + (size_t)nf * 64 * a.nblk);
     if (smem > 160 * 1024) return fail(RT_E_UNSUPPORTED, "ray pool of %zu bytes exceeds the 160 KiB LDS", smem);
 
     // Small frames (few pixel-samples, each a ray tree of up to thousands of rays: 640x480x1 has 307 200 trees of up to

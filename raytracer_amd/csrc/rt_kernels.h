@@ -156,14 +156,18 @@ constexpr int slots_of(bool bvh, int ring) { return (!bvh || ring == 8) ? 32 : 6
 
 // LDS of one wave, in dwords: slot table, lane map, record pool
 struct LdsLayout {
-    int acc, ps, pix, pend, map, pool;
-    constexpr explicit LdsLayout(int slots)
-        : acc(0),                    // u64 [slots*3]  radiance of the pixel-sample, 32.32
-          ps(slots * 6),             // u64 [slots]    global pixel-sample index (RNG counter)
-          pix(slots * 8),            // u32 [slots]    compact pixel index (k*H + py)
-          pend(slots * 9),           // u32 [slots]    records of this slot in the pool or in flight
-          map(slots * 10),           // u32 [64]       lane map (children / slot allocation)
-          pool(slots * 10 + 64) {}   // records, in blocks of 64
+    int stack, acc, ps, pix, pend, map, pool;
+    // `ring` = entries of a lane's traversal stack kept in LDS (0: linear-scan kernels).  The stack comes FIRST: its rows
+    // are 256 bytes and the 8-entry ring is addressed as (column base) | (row << 8) (rt_bvh.h RING2), which needs bits
+    // 8..10 of every column base to be zero.
+    constexpr LdsLayout(int slots, int ring)
+        : stack(0),                              // u32 [ring][64]  traversal stacks, one column per lane
+          acc(ring * 64),                        // u64 [slots*3]  radiance of the pixel-sample, 32.32
+          ps(ring * 64 + slots * 6),             // u64 [slots]    global pixel-sample index (RNG counter)
+          pix(ring * 64 + slots * 8),            // u32 [slots]    compact pixel index (k*H + py)
+          pend(ring * 64 + slots * 9),           // u32 [slots]    records of this slot in the pool or in flight
+          map(ring * 64 + slots * 10),           // u32 [64]       lane map (children / slot allocation)
+          pool(ring * 64 + slots * 10 + 64) {}   // records, in blocks of 64
 };
 
 // NODE64 = keep the ray-tree node index in 64 bits (needed when max_trace_depth > 13).
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     const int lane = threadIdx.x;
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     constexpr int SLOTS = slots_of(BVH, RING);
-    constexpr LdsLayout L(SLOTS);
+    constexpr LdsLayout L(SLOTS, BVH ? RING : 0);
     unsigned long long* sl_acc = reinterpret_cast<unsigned long long*>(smem + L.acc);
     unsigned long long* sl_ps = reinterpret_cast<unsigned long long*>(smem + L.ps);
     uint32_t* sl_pix = smem + L.pix;
@@ -214,7 +218,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
     };
     enum { F_PX = 0, F_PY = 64, F_PZ = 128, F_DX = 192, F_DY = 256, F_DZ = 320, F_BX = 384, F_BY = 448, F_BZ = 512,
            F_META = 576, F_NODE = 640, F_NODEHI = 704, F_SURF = NODE64 ? 768 : 704 };
-    uint32_t* bvh_stack = pool + a.nblk * (NF * 64) + lane;          // [RING][64], only when BVH
+    uint32_t* bvh_stack = smem + L.stack + lane;                     // [RING][64], only when BVH
+    if (BVH && RING == 8 && RT_BVH_RING2 && (lds_addr_of(smem + L.stack) & 0x7ffu) != 0u) {
+        // (cannot happen: the kernels have no static LDS, so the dynamic segment starts at byte 0)
+        if (lane == 0) atomicOr(cold_args()->status, kStatusOverflow);
+        return;
+    }
 
     const int spp = a.spp;
     const unsigned long long t_start = __builtin_readcyclecounter();
