@@ -36,9 +36,23 @@ struct BvhRef {
 };
 
 constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a leaf ref)
+// References as the device sees them (rt_scene_create rewrites the builder's): HALF THE BYTE OFFSET of the child from the
+// start of the allocation — node index << 6 for an inner node, (offset of the leaf's first record / 16) << 3 | count with
+// bit 31 set for a leaf — so that (ref & 0x7ffffff8) << 1 is the address of either, without a branch, a multiply by 48 or
+// the records' base (0: A/B build, node indices and record indices as the builder writes them).
+#ifndef RT_BVH_REF_OFFSETS
+#define RT_BVH_REF_OFFSETS 1
+#endif
+static_assert(!RT_BVH_REF_OFFSETS || kBvhLeafMax == 2, "(ref & 2) * 24 is the offset of a leaf's second record");
 // lanes that must have gathered at an inner node / at a leaf for that group to step (measured on the 100k-triangle, mixed
 // and 1M-sphere scenes; re-tuned in round 2, when the rounds had become cheaper: 16/16 -> 16/8 is +3 % on the mixed scene)
-constexpr int kBvhInnerMin = 16, kBvhLeafMin = 8;
+#ifndef RT_BVH_INNER_MIN
+#define RT_BVH_INNER_MIN 16
+#endif
+#ifndef RT_BVH_LEAF_MIN
+#define RT_BVH_LEAF_MIN 8
+#endif
+constexpr int kBvhInnerMin = RT_BVH_INNER_MIN, kBvhLeafMin = RT_BVH_LEAF_MIN;
 constexpr int kBvhStack = 64;             // host guarantees 3 * (tree depth) + 1 <= kBvhStack
 // EXPERIMENT (profiles/r03_node_bytes.txt): log2 of the bytes from one node to the next.  7 = the 128-byte node itself;
 // 8 = the same nodes 256 bytes apart (twice the node footprint in the caches at exactly the same instruction stream),
@@ -348,7 +362,11 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     auto issue = [&]() {
         if (do_in | do_leaf) {
             uint32_t o0, o1;        // inner: the node; leaf: first and second record
-            if (do_in) { o0 = cur << kBvhNodeShift; o1 = o0; }             // 128 bytes per node; the allocation is < 4 GB (host check)
+            if (RT_BVH_REF_OFFSETS) {
+                o0 = (cur & 0x7ffffff8u) << 1;
+                o1 = o0 + (cur & 2u) * 24u;                     // the second record of a two-record leaf (an inner reference has no low bits)
+            }
+            else if (do_in) { o0 = cur << kBvhNodeShift; o1 = o0; }             // 128 bytes per node; the allocation is < 4 GB (host check)
             else {
                 const uint32_t first = (cur & 0x7fffffffu) >> 3;
                 o0 = bvh.pdata_off + first * 48u;              // 48-byte records

@@ -746,6 +746,20 @@ int rt_scene_create(const rt_surface* surfaces, int64_t n, int32_t device, rt_sc
         }
         const size_t nbytes = sizeof(float4) * hb.nodes.size(), pbytes = sizeof(float4) * hb.pdata.size();
         sc->pdata_off = (uint32_t)nbytes;
+        if (RT_BVH_REF_OFFSETS) {
+            // the references the traversal sees: half the byte offset of the node / of the leaf's first record from the
+            // start of the allocation (rt_bvh.h: one mask and one shift give either address), leaf flag and count kept
+            const size_t stride4 = (size_t)1 << (kBvhNodeShift - 4), nn = hb.nodes.size() / stride4;
+            for (size_t i = 0; i < nn; i++) {
+                uint32_t refs[4];
+                memcpy(refs, &hb.nodes[i * stride4 + node_row(6) / 16], sizeof refs);
+                for (uint32_t& r : refs) {
+                    if (r & 0x80000000u) r = 0x80000000u | (uint32_t)((((size_t)nbytes + (size_t)((r & 0x7fffffffu) >> 3) * 48u) / 16u) << 3) | (r & 7u);
+                    else r = r << (kBvhNodeShift - 1);
+                }
+                memcpy(&hb.nodes[i * stride4 + node_row(6) / 16], refs, sizeof refs);
+            }
+        }
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sc->d_nodes), nbytes + pbytes);
         if (e == hipSuccess) e = hipMemcpy(sc->d_nodes, hb.nodes.data(), nbytes, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(reinterpret_cast<char*>(sc->d_nodes) + nbytes, hb.pdata.data(), pbytes, hipMemcpyHostToDevice);
