@@ -383,6 +383,9 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             d[0] = *reinterpret_cast<const float4*>(node_bytes + a0); d[1] = *reinterpret_cast<const float4*>(node_bytes + a1);
             d[2] = *reinterpret_cast<const float4*>(node_bytes + a2); d[3] = *reinterpret_cast<const float4*>(node_bytes + a3);
             d[4] = *reinterpret_cast<const float4*>(node_bytes + a4); d[5] = *reinterpret_cast<const float4*>(node_bytes + a5);
+            // (a leaf lane's seventh request fetches the last 16 bytes of its second record again.  Leaving it out — one
+            // exec-mask toggle — was measured: c4 -0.2 %, c3 -0.4 %, although the L1 serves only four 16-byte lane-requests
+            // per clock whatever their addresses, tools/gather_rate.hip: the request rate is not what bounds a round.)
             d[6] = *reinterpret_cast<const float4*>(node_bytes + a6);
         }
     };

@@ -70,6 +70,8 @@ int main(int argc, char** argv)
             run<1>(d_nodes, n - 1, w, visits, 0, d_out, lds);
         }
         run<7>(d_nodes, n - 1, 16, visits, 1, d_out, 10240);
+        // latency: few waves per CU (one 64 KB workgroup per wave so that they spread over the CUs)
+        for (int w : { 1, 2, 4, 8 }) { run<7>(d_nodes, n - 1, w, visits, 0, d_out, 10240); run<1>(d_nodes, n - 1, w, visits, 0, d_out, 10240); }
         hipFree(d_nodes);
     }
     return 0;
