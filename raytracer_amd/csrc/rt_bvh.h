@@ -40,6 +40,9 @@ constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a lea
 // start of the allocation — node index << 6 for an inner node, (offset of the leaf's first record / 16) << 3 | count with
 // bit 31 set for a leaf — so that (ref & 0x7ffffff8) << 1 is the address of either, without a branch, a multiply by 48 or
 // the records' base (0: A/B build, node indices and record indices as the builder writes them).
+#ifndef RT_BVH_LATE_SORT
+#define RT_BVH_LATE_SORT 1    // 0: A/B build, the whole sort before the next round's loads
+#endif
 #ifndef RT_BVH_REF_OFFSETS
 #define RT_BVH_REF_OFFSETS 1
 #endif
@@ -395,6 +398,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         // what this round's inner lanes still have to push once the next loads are under way
         bool pushing = do_in;
         uint32_t p0 = 0u, p1 = 0u, p2 = 0u; int nh = 0;
+        float lt1 = kFltMax, lt2 = kFltMax, lt3 = kFltMax;
         if (do_in) {
             // ---- inner node: four slab tests
             const float4 nx4 = d[0], fx4 = d[1], ny4 = d[2], fy4 = d[3], nz4 = d[4], fz4 = d[5], rf = d[6];
@@ -406,13 +410,20 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             box_entry2(v2f{ nx4.z, nx4.w }, v2f{ ny4.z, ny4.w }, v2f{ nz4.z, nz4.w }, v2f{ fx4.z, fx4.w }, v2f{ fy4.z, fy4.w }, v2f{ fz4.z, fz4.w },
                        mx, my, mz, cx, cy, cz, tmaxw, t2, t3);
             // sort the four by entry distance (5 compare-exchanges); misses (kFltMax) go last
-            sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2); sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
-            // the hits are a prefix of the sorted four: descend into the nearest, push the others far to near (below).
-            // A lane pushes (it has a hit and descends) or pops (it has none), never both in one round.
-            const bool h2 = t2 < kFltMax, h3 = t3 < kFltMax;
-            nh = (t1 < kFltMax ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
-            if (RING2) { p0 = r3; p1 = r2; p2 = r1; pushing = nh != 0; nh <<= 8; }   // the sorted three as they are (below)
-            else { p0 = h3 ? r3 : (h2 ? r2 : r1); p1 = h3 ? r2 : r1; p2 = r1; }
+            sort2(t0, r0, t1, r1); sort2(t2, r2, t3, r3); sort2(t0, r0, t2, r2);
+            if (RING2 && RT_BVH_LATE_SORT) {
+                // the nearest child is known after three of the five exchanges, and it is all the next round's loads wait
+                // for: the last two, the hit count and the pushes run after those loads are issued (below)
+                lt1 = t1; lt2 = t2; lt3 = t3; p0 = r3; p1 = r2; p2 = r1;
+            } else {
+                sort2(t1, r1, t3, r3); sort2(t1, r1, t2, r2);
+                // the hits are a prefix of the sorted four: descend into the nearest, push the others far to near (below).
+                // A lane pushes (it has a hit and descends) or pops (it has none), never both in one round.
+                const bool h2 = t2 < kFltMax, h3 = t3 < kFltMax;
+                nh = (t1 < kFltMax ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+                if (RING2) { p0 = r3; p1 = r2; p2 = r1; pushing = nh != 0; nh <<= 8; }   // the sorted three as they are (below)
+                else { p0 = h3 ? r3 : (h2 ? r2 : r1); p1 = h3 ? r2 : r1; p2 = r1; }
+            }
             cur = (t0 < kFltMax) ? r0 : pop();
         }
         if (do_leaf) {
@@ -441,6 +452,11 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
             // fewer than three hits the later, valid stores overwrite the earlier ones and nothing is written outside
             // [sp, sp + nh).  (Before: three selects for the values, three for dump-or-ring addresses, nine address
             // operations: 22 vector instructions per inner round, now 9.)
+            if (RT_BVH_LATE_SORT && pushing) {
+                sort2(lt1, p2, lt3, p0); sort2(lt1, p2, lt2, p1);      // (p2, p1, p0) = the second, third and fourth nearest
+                nh = ((lt1 < kFltMax ? 1 : 0) + (lt2 < kFltMax ? 1 : 0) + (lt3 < kFltMax ? 1 : 0)) << 8;
+                pushing = nh != 0;
+            }
             if (pushing) {
                 while (sp + nh - lo > K * 256) { backing()[lo >> 2] = lds_load(l4 | ((uint32_t)lo & 0x700u)); lo += 256; }
                 const int nsp = sp + nh;
