@@ -340,6 +340,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     bool do_in = false, do_leaf = false;
     float4 d[7];
     // decide(): which groups step in the coming round (false: leave the traversal); issue(): their loads
+    int st_in = 0, st_lf = 0;       // lanes stepping at an inner node / at a leaf in the round just decided
     auto decide = [&]() -> bool {
         // (a leaf reference is 0x80000000 | first << 3 | count with count >= 1 and first < 2^28: as an int it is below -1 = kBvhDone)
         const bool in = (int)cur >= 0, lf = (int)cur < -1;
@@ -350,12 +351,15 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         const bool step_lf = (n_lf >= LEAF_MIN) | (n_lf > n_in);
         do_in = in & step_in;
         do_leaf = lf & step_lf;
-        // wave-uniform statistics (scalar arithmetic)
-        rounds_inner += (step_in && n_in != 0) ? 1u : 0u;
-        rounds_leaf += (step_lf && n_lf != 0) ? 1u : 0u;
-        nodes_visited += step_in ? (uint32_t)n_in : 0u;
-        if (step_lf) prims_tested += (uint32_t)n_lf + (uint32_t)popc_mask(__ballot(lf & ((cur & 6u) != 0u)));   // leaves hold 1 or 2
+        st_in = step_in ? n_in : 0; st_lf = step_lf ? n_lf : 0;      // for account(), once the loads are under way
         return true;
+    };
+    // wave-uniform statistics of the round just decided (scalar arithmetic), off the load -> decide -> load chain
+    auto account = [&]() {
+        rounds_inner += (st_in != 0) ? 1u : 0u;
+        rounds_leaf += (st_lf != 0) ? 1u : 0u;
+        nodes_visited += (uint32_t)st_in;
+        if (st_lf != 0) prims_tested += (uint32_t)st_lf + (uint32_t)popc_mask(__ballot(do_leaf & ((cur & 6u) != 0u)));   // leaves hold 1 or 2
     };
     // Both groups load through the SAME seven 16-byte requests, each lane from its own addresses: a lane at an inner
     // node the six plane vectors and the references of its node, a lane at a leaf its (up to) two records of three
@@ -394,6 +398,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     };
     if (!decide()) return;
     issue();
+    account();
     while (true) {
         // what this round's inner lanes still have to push once the next loads are under way
         bool pushing = do_in;
@@ -442,7 +447,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         }
         // ---- next round: decision and loads
         const bool more = decide();
-        if (more) issue();
+        if (more) { issue(); account(); }
         // ---- this round's pushes.  Branch-free: three entries are always stored, those beyond the new top are garbage in
         // free slots.
         if (RING2) {
