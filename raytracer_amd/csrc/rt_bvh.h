@@ -238,6 +238,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
                             uint32_t& nodes_visited, uint32_t& prims_tested, uint32_t& rounds_inner, uint32_t& rounds_leaf)
 {
     static_assert((K & (K - 1)) == 0, "ring size must be a power of two");
+
     // The ray as a cone.  The reference's sphere test (Sphere.fs:18-43, prim_test) computes d = b^2 - C from two numbers
     // of size L^2, L = |O - centre|: 15 roundings of relative 2^-24 on terms <= L^2, and |D|^2 - 1 (<= 2.4e-7 for a
     // direction normalised in f32), put up to k L^2, k = 1.2e-6, between d and its exact value.  So the linear scan accepts
