@@ -288,6 +288,15 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         sc.status()
+        # The timed frames count what renderScene itself produces (rays, largest depth).  The inputs of the flop model —
+        # rays by kind, BVH node visits and primitive tests, loop iterations — come from ONE more frame of the same
+        # workload rendered with every counter on (rt_scene_counters; 1-3 % slower, outside the timed region): the ray
+        # trees, and with them those counts, are identical from frame to frame.
+        lean_rays = diag["rays"]
+        sc.counters(1)
+        step(sc, cols, bufs, g)
+        sc.status()
+        assert diag["rays"] == lean_rays, (diag["rays"], lean_rays)
         kern_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
         gather_ms = sum(e[2].elapsed_time(e[3]) for e in evs) / steps
         tt = torch.tensor([dt], dtype=torch.float64, device=gdev)
@@ -331,6 +340,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / VALU_PEAK_TFLOPS, "traffic": measured_traffic(args.workload) if world == 1 else None,
                          "kernel": "rt::trace_kernel (+ memsets and rt::resolve_kernel, <1 % of the bracket)",
+                         "counts_from": "one extra frame of the same workload with rt_scene_counters(1), after the timed region (identical ray trees; the timed frames count rays and largest depth only)",
                          "peak_note": PEAK_NOTE,
                          "kernel_ms": kern_ms, "flops_per_launch": flops, "flops_per_ray": flops / max(1, diag["rays"]),
                          "rays_by_kind": {"lambertian": diag["lamb"], "metal": diag["metal"], "dielectric": diag["diel"],

@@ -1,4 +1,4 @@
-// Native.fs — P/Invoke surface of librt_hip.so (include/rt_abi.h, RT_ABI_VERSION 7) for the reference's F# host.
+// Native.fs — P/Invoke surface of librt_hip.so (include/rt_abi.h, RT_ABI_VERSION 8) for the reference's F# host.
 //
 // Compile position: after Surface.fs / SceneDefinitions.fs and before SceneGpu.fs (see raytracer.gpu.fsproj).
 // Every struct below is BLITTABLE: only primitive fields and System.Numerics Vector3 / Vector4 / Matrix4x4 (which are
@@ -55,7 +55,7 @@ type RtParams =
     val mutable twoPass : int32
 
 [<Literal>]
-let RtAbiVersion = 7
+let RtAbiVersion = 8
 
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
 extern int rt_abi_version()
@@ -67,6 +67,9 @@ extern int rt_scene_create(RtSurface[] surfaces, int64 n, int32 device, nativein
 extern void rt_scene_destroy(nativeint scene)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
 extern int rt_scene_status(nativeint scene)
+// 0 (default): frames count their rays and largest depth only; 1: every word of the statistics array (1-3 % slower)
+[<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
+extern int rt_scene_counters(nativeint scene, int32 level)
 // optional: pinned host memory for the frame buffers (PinnedArray2D below)
 [<DllImport("rt_hip", CallingConvention = CallingConvention.Cdecl)>]
 extern int rt_host_alloc(uint64 bytes, nativeint& out)

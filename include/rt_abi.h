@@ -155,7 +155,8 @@ int  rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
  * tested (0 for linear-scan scenes), [10] / [11] BVH traversal rounds with an inner-node / a leaf step,
  * [12..15] shader clocks summed over waves in the phases generate / plane scan / BVH traversal / shade+flush
  * (filled by builds with -DRT_PHASE_TIMING, else 0), [16], [17] unused, [18] the longest wave lifetime in shader clocks
- * ([6] / [7] is the mean), [19] unused; may be NULL.
+ * ([6] / [7] is the mean), [19] unused; may be NULL.  Words [2]..[5] and [8]..[11] stay 0 unless rt_scene_counters(scene, 1)
+ * was called (below).
  * No counterpart in the reference.                                                            */
 #define RT_STATS_WORDS 20
 int  rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
@@ -208,6 +209,14 @@ int  rt_find_closest(rt_scene* scene, int64_t nrays, const float* origins, const
  * spill capacity at all, so that this path runs: tests/test_gpu_overflow.py.)                                    */
 int  rt_scene_status(rt_scene* scene);
 
+/* Which words of d_stats the frames of `scene` fill.  level 0 (the default): the ray count [0], the largest depth [1] and
+ * the wave clocks [6], [7], [18] — what `Scene.renderScene` itself produces (Scene.fs:47-48) plus what it costs; level 1:
+ * every word (rays by kind, loop iterations, BVH visits and rounds: the inputs of bench.py's flop model).  The image, the
+ * depth buffer, the IDs and words [0], [1] do not depend on the level; the extra counters cost a frame 1-3 % (they are
+ * wave-uniform scalars carried through the whole render loop), which is why a frame does not pay for them unless asked.
+ * Takes effect from the next render of the handle.  NO counterpart in the reference.                              */
+int  rt_scene_counters(rt_scene* scene, int level);
+
 /* Optional: pinned host memory for the frame buffers (hipHostMalloc / hipHostFree).  rt_render and rt_render_multi copy
  * a frame into buffers that live in such a block by DMA instead of through the runtime's pageable path (640x480x1:
  * rgba + depth in 0.13 instead of 0.45 ms).  NO counterpart in the reference, whose `frameBuffer` / `depthBuffer`
@@ -224,7 +233,7 @@ const char* rt_last_error(void);
 
 /* ABI version: bumped whenever a struct layout or signature changes.                         */
 int  rt_abi_version(void);
-#define RT_ABI_VERSION 7
+#define RT_ABI_VERSION 8
 
 #ifdef __cplusplus
 }

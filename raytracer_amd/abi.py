@@ -21,7 +21,7 @@ ESTIMATOR_BRANCHING, ESTIMATOR_SINGLE_PATH = 0, 1
 KIND_NOSURFACE, KIND_LAMBERTIAN, KIND_METAL, KIND_DIELECTRIC = 0, 1, 2, 3
 GEOM_SPHERE, GEOM_PLANE, GEOM_TRIANGLE = 0, 1, 2
 
-RT_ABI_VERSION = 7
+RT_ABI_VERSION = 8
 RT_STATS_WORDS = 20
 RT_NOALLOC_SCRATCH_BYTES = 64 << 20
 RT_NOALLOC_MAX_PIXELS = 1 << 20
@@ -102,6 +102,7 @@ ABI_SYMBOLS = (
     "rt_render_multi",
     "rt_find_closest",
     "rt_scene_status",
+    "rt_scene_counters",
     "rt_host_alloc",
     "rt_host_free",
     "rt_scene_destroy",
@@ -141,6 +142,8 @@ def load_hip_library():
     lib.rt_find_closest.restype = C.c_int
     lib.rt_scene_status.argtypes = [C.c_void_p]
     lib.rt_scene_status.restype = C.c_int
+    lib.rt_scene_counters.argtypes = [C.c_void_p, C.c_int]
+    lib.rt_scene_counters.restype = C.c_int
     lib.rt_host_alloc.argtypes = [C.c_uint64, P(C.c_void_p)]
     lib.rt_host_alloc.restype = C.c_int
     lib.rt_host_free.argtypes = [C.c_void_p]

@@ -232,7 +232,9 @@ constexpr uint32_t kBvhDone = 0xffffffffu;
 //
 // `cur`/`sp`/`lo` are the lane's traversal state: cur = kBvhDone: no ray, 0: at the root.  The call returns
 // when no lane is walking or fewer than `min_active` are; those continue in the next call.
-template <int K, bool SPILL, int IN_MIN, int LEAF_MIN, typename Backing>
+// COUNT: keep the statistics (nodes visited, primitives tested, rounds); a scene renders without them unless
+// rt_scene_counters asked for them (the counters cost the mesh frames 2-3 %).
+template <int K, bool SPILL, int IN_MIN, int LEAF_MIN, bool COUNT, typename Backing>
 RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int stride, uint32_t* dump, Backing backing,
                             float& tmin, int& idx, uint32_t& cur, int& sp, int& lo, int min_active,
                             uint32_t& nodes_visited, uint32_t& prims_tested, uint32_t& rounds_inner, uint32_t& rounds_leaf)
@@ -357,6 +359,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     };
     // wave-uniform statistics of the round just decided (scalar arithmetic), off the load -> decide -> load chain
     auto account = [&]() {
+        if (!COUNT) return;
         rounds_inner += (st_in != 0) ? 1u : 0u;
         rounds_leaf += (st_lf != 0) ? 1u : 0u;
         nodes_visited += (uint32_t)st_in;

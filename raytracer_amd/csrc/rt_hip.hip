@@ -161,8 +161,9 @@ struct rt_scene {
     float lin_s = 0.0f, lin_far = 3.402823466e38f;
     float cone_k = 0.0f, tree_rmin = 0.0f, tree_rmax = 0.0f, tree_reach = 0.0f;    // spheres in the tree: how the traversal widens the ray (rt_bvh.h closest_hit_bvh)
     int64_t nprims = 0;                        // primitives in the BVH
-    int occ_smem[32] = { 0 };         // (0 = not queried yet) LDS size the cached occupancy below was queried for (per kernel variant)
-    int occ_per_cu[32] = { 0 };
+    int counters = 0;                 // rt_scene_counters: 1 = the frames of this scene fill every word of d_stats
+    int occ_smem[64] = { 0 };         // (0 = not queried yet) LDS size the cached occupancy below was queried for (per kernel variant)
+    int occ_per_cu[64] = { 0 };
     unsigned char* d_list = nullptr;    // small frames: hit records of the primary pass (grown on demand)
     size_t list_bytes = 0;
     float* d_tmp = nullptr;             // rt_render / rt_find_closest staging (grown on demand)
@@ -249,15 +250,15 @@ constexpr long long kSampleMajorBelow = RT_SAMPLE_MAJOR_BELOW;   // pixel-sample
 
 // PHASE: 0 = one launch per frame; 1, 2 = the two passes of a small frame; 3 = one launch, handed out sample-major (trace_kernel)
 // SINGLE: the single-path estimator (rt_params.estimator)
-template <bool NODE64, bool BVH, int RING, int PHASE, bool SINGLE>
+template <bool NODE64, bool BVH, int RING, int PHASE, bool SINGLE, bool COUNT>
 int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_cu,
                  size_t smem, hipStream_t stream, const Workspace& ws)
 {
     constexpr int phase = PHASE;
-    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING, PHASE, SINGLE>);
+    const void* fn = reinterpret_cast<const void*>(&trace_kernel<NODE64, BVH, RING, PHASE, SINGLE, COUNT>);
     constexpr int NF = 11 + (NODE64 ? 1 : 0) + (BVH ? 1 : 0);
     // the attribute and the occupancy query cost host time: once per (kernel, LDS size) and scene
-    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE + (SINGLE ? 16 : 0);
+    constexpr int variant = (NODE64 ? 1 : 0) + ((BVH && RING == 16) ? 2 : 0) + 4 * PHASE + (SINGLE ? 16 : 0) + (COUNT ? 32 : 0);
     int& cached_smem = sc->occ_smem[variant];
     int& cached_per_cu = sc->occ_per_cu[variant];
     {   // hipFuncAttributeMaxDynamicSharedMemorySize belongs to the KERNEL (per device), not to a scene: two scenes that
@@ -334,7 +335,7 @@ int launch_trace(rt_scene* sc, ColdArgs& c, const RenderArgs& a, int waves_per_c
     c.group_shift = 0;
     if (a.max_depth <= kDeepTrace)
         while (c.group_shift < (BVH ? kBvhGroupShift : kLinGroupShift) && a.spp % (2 << c.group_shift) == 0) c.group_shift++;
-    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING, PHASE, SINGLE>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
+    hipLaunchKernelGGL((trace_kernel<NODE64, BVH, RING, PHASE, SINGLE, COUNT>), dim3((unsigned)grid), dim3(64), smem, stream, c, a, sc->d_geom, sc->d_shade,
                        bvh_ref(sc));
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -481,16 +482,21 @@ int render_on_stream(rt_scene* sc, const rt_camera* cam, const rt_params* p, hip
         HIP_TRY(hipMemsetAsync(c.list + 9 * list_cap, 0, list_cap * sizeof(uint32_t), stream));
     }
 
-    auto launch_est = [&](auto phase_tag, auto est_tag) -> int {
+    auto launch_cnt = [&](auto phase_tag, auto est_tag, auto cnt_tag) -> int {
         constexpr int PH = decltype(phase_tag)::value;
         constexpr bool SP = decltype(est_tag)::value;
+        constexpr bool CN = decltype(cnt_tag)::value;
         if (sc->use_bvh)
-            return ring == 8 ? (node64 ? launch_trace<true, true, 8, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                                       : launch_trace<false, true, 8, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws))
-                             : (node64 ? launch_trace<true, true, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                                       : launch_trace<false, true, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws));
-        return node64 ? launch_trace<true, false, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws)
-                      : launch_trace<false, false, 16, PH, SP>(sc, c, a, p->waves_per_cu, smem, stream, ws);
+            return ring == 8 ? (node64 ? launch_trace<true, true, 8, PH, SP, CN>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                       : launch_trace<false, true, 8, PH, SP, CN>(sc, c, a, p->waves_per_cu, smem, stream, ws))
+                             : (node64 ? launch_trace<true, true, 16, PH, SP, CN>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                                       : launch_trace<false, true, 16, PH, SP, CN>(sc, c, a, p->waves_per_cu, smem, stream, ws));
+        return node64 ? launch_trace<true, false, 16, PH, SP, CN>(sc, c, a, p->waves_per_cu, smem, stream, ws)
+                      : launch_trace<false, false, 16, PH, SP, CN>(sc, c, a, p->waves_per_cu, smem, stream, ws);
+    };
+    auto launch_est = [&](auto phase_tag, auto est_tag) -> int {
+        // all the statistics only for a scene that asked for them and a caller that takes them (rt_scene_counters)
+        return (sc->counters && d_stats) ? launch_cnt(phase_tag, est_tag, std::true_type()) : launch_cnt(phase_tag, est_tag, std::false_type());
     };
     auto launch = [&](auto phase_tag) -> int {
         return p->estimator == RT_ESTIMATOR_SINGLE_PATH ? launch_est(phase_tag, std::true_type()) : launch_est(phase_tag, std::false_type());
@@ -816,6 +822,14 @@ int rt_render_device_noalloc(rt_scene* sc, const rt_camera* cam, const rt_params
                              float* d_rgba, float* d_depth, uint64_t* d_object_id, uint64_t* d_stats)
 {
     return render_on_stream(sc, cam, p, static_cast<hipStream_t>(stream_v), d_rgba, d_depth, d_object_id, d_stats, true);
+}
+
+int rt_scene_counters(rt_scene* sc, int level)
+{
+    if (!sc) return fail(RT_E_INVALID, "scene is null");
+    if (level != 0 && level != 1) return fail(RT_E_INVALID, "counters level %d (0 or 1)", level);
+    sc->counters = level;
+    return RT_OK;
 }
 
 int rt_scene_status(rt_scene* sc)

@@ -177,7 +177,9 @@ struct LdsLayout {
 //          14 waves on a CU instead of 12 (the traversal is latency-bound: measured +10 % on the 4K mixed scene)
 //          at the price of a few spilled registers and of more stack traffic to HBM, which is why scenes with
 //          deep, crowded trees (the 1M-sphere field: -11 %) use the 16-entry variant at 3 waves per SIMD.
-template <bool NODE64, bool BVH, int RING, int PHASE, bool SINGLE>
+// COUNT  = all words of the statistics array (rays by kind, iterations, BVH visits and rounds); without it a frame counts
+//          its rays, its largest depth and the wave clocks only (rt_scene_counters: the counters cost 1-3 % of a frame).
+template <bool NODE64, bool BVH, int RING, int PHASE, bool SINGLE, bool COUNT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING == 8 ? 4 : 3) : 6))) void trace_kernel(const ColdArgs cold_unused, const RenderArgs a,
                                                    const GeomRec* __restrict__ geom,
                                                    const ShadeRec* __restrict__ shade, const BvhRef bvh)
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             if (PHASE == 2) continue;         // a hand-out without a valid entry (sky, lights): take the next one
             overflow = true; break;             // cannot happen (all slots are free here and the hand-out is not used up): never spin
         }
-        n_iter++;
+        if (COUNT) n_iter++;
         RT_FINE(2)   // refill atomic
         const bool is_child = !busy && frank < nchild;
         const bool fresh_prim = !busy && !is_child && frank < nchild + nprim;
@@ -637,9 +639,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         }
 
         // rays by kind (wave-uniform counts)
+        if (COUNT) {
         n_lamb += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindLambert));
         n_metal += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindMetal));
         n_diel += (uint32_t)popc_mask(__ballot(!busy && alive && ckind == kKindDielectric));
+        }
 
         // ============ findClosestIntersection + hit handling, all 64 lanes ============
         bool push = false;
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             // +0.7 %, the sample-major frames -0.9 % (mesh) and -1 % (1M spheres), which therefore keep the vector form.)
             int ma = refill ? a.min_active : 0;
             if (PHASE == 0) ma = __builtin_amdgcn_readfirstlane(ma);
-            closest_hit_bvh<RING, true, kBvhInnerMin, kBvhLeafMin>(bvh, O, Dn, bvh_stack, 64, map + lane, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
+            closest_hit_bvh<RING, true, kBvhInnerMin, kBvhLeafMin, COUNT>(bvh, O, Dn, bvh_stack, 64, map + lane, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
                                             ma, n_nodes, n_prims, n_rin, n_rlf);
             busy = alive && trav_cur != kBvhDone;
             busymask = __ballot(busy);
@@ -838,10 +842,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
         if (lane == 0) {
             atomicAdd(stats + 0, r);
             atomicMax(reinterpret_cast<unsigned int*>(stats + 1), __float_as_uint(m));
-            atomicAdd(stats + 2, (unsigned long long)n_iter);
-            atomicAdd(stats + 3, (unsigned long long)n_lamb);
-            atomicAdd(stats + 4, (unsigned long long)n_metal);
-            atomicAdd(stats + 5, (unsigned long long)n_diel);
+            if (COUNT) {
+                atomicAdd(stats + 2, (unsigned long long)n_iter);
+                atomicAdd(stats + 3, (unsigned long long)n_lamb);
+                atomicAdd(stats + 4, (unsigned long long)n_metal);
+                atomicAdd(stats + 5, (unsigned long long)n_diel);
+            }
             atomicAdd(stats + 6, __builtin_readcyclecounter() - t_start);
             atomicAdd(stats + 7, 1ull);
             atomicMax(stats + 18, __builtin_readcyclecounter() - t_start);
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 atomicAdd(stats + 19, 1ull);
             }
 #endif
-            if (BVH) {
+            if (BVH && COUNT) {
                 atomicAdd(stats + 8, nn); atomicAdd(stats + 9, np);
                 atomicAdd(stats + 10, (unsigned long long)n_rin); atomicAdd(stats + 11, (unsigned long long)n_rlf);
 #ifdef RT_PHASE_TIMING
@@ -942,7 +948,7 @@ __global__ __launch_bounds__(256) void find_closest_kernel(const GeomRec* __rest
     uint32_t nn = 0, np = 0;
     uint32_t cur = bvh.nnodes ? 0u : kBvhDone; int sp = 0, lo = 0;
     auto backing = []() -> uint32_t* { return nullptr; };
-    closest_hit_bvh<kBvhStack, false, 1, 1>(bvh, O, D, stack, 1, stack, backing, t, idx, cur, sp, lo, 0, nn, np, nn, np);
+    closest_hit_bvh<kBvhStack, false, 1, 1, false>(bvh, O, D, stack, 1, stack, backing, t, idx, cur, sp, lo, 0, nn, np, nn, np);
     t_out[i] = t; idx_out[i] = idx;
 }
 

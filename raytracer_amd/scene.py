@@ -147,6 +147,12 @@ class Scene:
         self.upload()
         abi.check(self._lib, self._lib.rt_scene_status(self._scene))
 
+    def counters(self, level):
+        """rt_scene_counters: 1 = the frames of this scene fill every word of d_stats (rays by kind, BVH visits ...),
+        0 (default) = ray count, largest depth and wave clocks only."""
+        self.upload()
+        abi.check(self._lib, self._lib.rt_scene_counters(self._scene, int(level)))
+
     def findClosestIntersection(self, origins, directions):
         """Batch form of Surface.fs:49-58 on the device: returns (t, index) arrays."""
         self.upload()

@@ -44,7 +44,7 @@ def test_no_kernel_spills_vector_registers_to_scratch():
         if m and cur:
             kernels[cur][m.group(1)] = int(m.group(2))
     trace = {k: v for k, v in kernels.items() if "trace_kernel" in k}
-    assert len(trace) == 48, sorted(kernels)          # {NODE64} x {linear, BVH ring 8, BVH ring 16} x {pass 0, 1, 2, 3} x {estimator}
+    assert len(trace) == 96, sorted(kernels)          # {NODE64} x {linear, BVH ring 8, BVH ring 16} x {pass 0, 1, 2, 3} x {estimator} x {counters}
     bodies = _kernel_bodies(os.path.join(csrc, "rt_hip.s"))
     for name, r in trace.items():
         assert r["VGPRs Spill"] == 0 and r["ScratchSize [bytes/lane]"] <= 64, (name, r)
