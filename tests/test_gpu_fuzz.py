@@ -66,6 +66,8 @@ def test_random_scene_and_parameters(case):
                seed=int(rng.integers(1, 1 << 40)), lambertian_samples=lamb, backgroundColor=bg, estimator=estimator,
                two_pass=int(rng.random() < 0.3), bvh_ring=int(rng.choice([0, 0, 16])),
                bvh_min_active=int(rng.choice([0, 0, 7, 40])), pool_blocks=int(rng.choice([0, 0, 3])), **camera)
+    if (_BASE + case) % 3 == 0:
+        sc.counters(1)                         # the instantiations with every statistic on (rt_scene_counters)
     _compare(sc)
     # a random interleaved column share renders exactly its columns of that frame
     n = int(rng.integers(2, 5)); r = int(rng.integers(0, n))
