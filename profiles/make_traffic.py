@@ -15,7 +15,9 @@ for path in sorted(glob.glob(os.path.join(ROOT, "profiles", tag + "_*_rocprof.js
     d = json.load(open(path))
     total, names = 0.0, []
     for k, c in d["counters"].items():
-        if "trace_kernel" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # (bench.py renders one more frame with every counter on — rt_scene_counters — after its timed frames: that
+        # launch is the instantiation whose last template argument is `true`, and is not what `traffic` describes)
+        if "trace_kernel" in k and k.split("(")[0].rstrip("> ").endswith(", false") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             total += (c["FETCH_SIZE"] * 2 + c["WRITE_SIZE"]) * 1024
             names.append(k)
     if names:
