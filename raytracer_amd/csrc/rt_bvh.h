@@ -43,6 +43,9 @@ constexpr int kBvhLeafMax = 2;           // primitives per leaf (3 bits in a lea
 #ifndef RT_BVH_LATE_SORT
 #define RT_BVH_LATE_SORT 1    // 0: A/B build, the whole sort before the next round's loads
 #endif
+#ifndef RT_BVH_ISSUE_ASM
+#define RT_BVH_ISSUE_ASM 1    // 0: A/B build, the addresses of a round's loads as the compiler writes them
+#endif
 #ifndef RT_BVH_REF_OFFSETS
 #define RT_BVH_REF_OFFSETS 1
 #endif
@@ -341,6 +344,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     // (The traversal is latency-bound at 4 waves per SIMD: frame rate is proportional to the waves per CU, so every
     // instruction taken off the load -> decide -> load chain counts.)
     bool do_in = false, do_leaf = false;
+    unsigned long long m_in = 0ull, m_lf = 0ull;
     float4 d[7];
     // decide(): which groups step in the coming round (false: leave the traversal); issue(): their loads
     int st_in = 0, st_lf = 0;       // lanes stepping at an inner node / at a leaf in the round just decided
@@ -354,6 +358,8 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
         const bool step_lf = (n_lf >= LEAF_MIN) | (n_lf > n_in);
         do_in = in & step_in;
         do_leaf = lf & step_lf;
+        m_in = step_in ? __ballot(in) : 0ull;        // the same as wave-uniform masks, for issue() (not carried around the loop)
+        m_lf = step_lf ? __ballot(lf) : 0ull;
         st_in = step_in ? n_in : 0; st_lf = step_lf ? n_lf : 0;      // for account(), once the loads are under way
         return true;
     };
@@ -371,7 +377,7 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
     // One set of 28 registers instead of two sets (28 + 24) in flight, seven VMEM instructions per round instead of
     // thirteen when both groups step.
     auto issue = [&]() {
-        if (do_in | do_leaf) {
+        if (RT_BVH_ISSUE_ASM ? __builtin_amdgcn_inverse_ballot_w64(m_in | m_lf) : (do_in | do_leaf)) {
             uint32_t o0, o1;        // inner: the node; leaf: first and second record
             if (RT_BVH_REF_OFFSETS) {
                 o0 = (cur & 0x7ffffff8u) << 1;
@@ -384,9 +390,21 @@ RT_DEV void closest_hit_bvh(const BvhRef& bvh, f3 O, f3 D, uint32_t* stack, int 
                 o1 = o0 + (((cur & 6u) != 0u) ? 48u : 0u);
             }
 #if RT_BVH_PACK_OFF
-            const uint32_t f0 = do_in ? in_off0 : kLeafOff0, f1 = do_in ? in_off1 : kLeafOff1;
+            // (the selects read the step decision as the scalar mask decide() has just made, not the 0/1 flag carried
+            // around the loop, which costs a v_and and a v_cmp per test)
+            const bool sel_in = RT_BVH_ISSUE_ASM ? __builtin_amdgcn_inverse_ballot_w64(m_in) : do_in;
+            const uint32_t f0 = sel_in ? in_off0 : kLeafOff0, f1 = sel_in ? in_off1 : kLeafOff1;
+#if RT_BVH_ISSUE_ASM
+            // one add with a byte select per address (the compiler takes three instructions for four of the seven)
+            uint32_t a0, a1, a2, a3, a4, a5, a6;
+#define RT_ADD_BYTE(dst, base, packed, sel) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" sel : "=v"(dst) : "v"(base), "v"(packed))
+            RT_ADD_BYTE(a0, o0, f0, "BYTE_0"); RT_ADD_BYTE(a1, o0, f0, "BYTE_1"); RT_ADD_BYTE(a2, o0, f0, "BYTE_2");
+            RT_ADD_BYTE(a3, o1, f1, "BYTE_0"); RT_ADD_BYTE(a4, o1, f1, "BYTE_1"); RT_ADD_BYTE(a5, o1, f1, "BYTE_2"); RT_ADD_BYTE(a6, o1, f1, "BYTE_3");
+#undef RT_ADD_BYTE
+#else
             const uint32_t a0 = o0 + (f0 & 0xffu), a1 = o0 + ((f0 >> 8) & 0xffu), a2 = o0 + ((f0 >> 16) & 0xffu);
             const uint32_t a3 = o1 + (f1 & 0xffu), a4 = o1 + ((f1 >> 8) & 0xffu), a5 = o1 + ((f1 >> 16) & 0xffu), a6 = o1 + (f1 >> 24);
+#endif
 #else
             const uint32_t a0 = o0 + (do_in ? onx : 0u), a1 = o0 + (do_in ? ofx : 16u), a2 = o0 + (do_in ? ony : 32u);
             const uint32_t a3 = o1 + (do_in ? ofy : 0u), a4 = o1 + (do_in ? onz : 16u), a5 = o1 + (do_in ? ofz : 32u), a6 = o1 + (do_in ? node_row(6) : 32u);
