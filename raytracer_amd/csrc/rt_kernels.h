@@ -128,6 +128,10 @@ RT_DEV uint32_t make_meta(int slot, int level, int n, int kind, int geom, int su
            ((uint32_t)geom << 18) | ((uint32_t)surf << 20);
 }
 
+// A 64-bit zero made where it is stored: as a plain constant the compiler keeps it in a register pair for the whole render
+// loop (and, when registers run out, spills THAT to scratch rather than making it again).
+RT_DEV unsigned long long local_zero() { unsigned long long z = 0ull; asm volatile("" : "+v"(z)); return z; }
+
 RT_DEV int mbcnt64(unsigned long long m)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                     sl_ps[sl] = (unsigned long long)lr[NF * cap] | ((unsigned long long)lr[(NF + 1) * cap] << 32);
                     sl_pix[sl] = lr[(NF + 2) * cap];
                     sl_pend[sl] = 1u;
-                    sl_acc[sl * 3 + 0] = 0ull; sl_acc[sl * 3 + 1] = 0ull; sl_acc[sl * 3 + 2] = 0ull;
+                    { const unsigned long long z = local_zero(); sl_acc[sl * 3 + 0] = z; sl_acc[sl * 3 + 1] = z; sl_acc[sl * 3 + 2] = z; }
                 }
                 top += nv;
                 __syncthreads();
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 sl_ps[slot] = pixel * (uint64_t)spp + (uint64_t)s;
                 sl_pix[slot] = o;
                 sl_pend[slot] = 1u;
-                sl_acc[slot * 3 + 0] = 0ull; sl_acc[slot * 3 + 1] = 0ull; sl_acc[slot * 3 + 2] = 0ull;
+                { const unsigned long long z = local_zero(); sl_acc[slot * 3 + 0] = z; sl_acc[slot * 3 + 1] = z; sl_acc[slot * 3 + 2] = z; }
                 f3 rv = F3(0.0f, 0.0f, 0.0f);
                 if (ca->jitter) rv = unit_sphere_sample(a.seed_lo, a.seed_hi, pixel);
                 const float fw = ca->fw, fh = ca->fh, tan_half = ca->tan_half;
@@ -812,8 +816,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
                 const int ndone = popc_mask(dm);
                 if (done) map[mbcnt64(dm)] = (uint32_t)slot;
                 __syncthreads();
+                int fl = lane;
+                asm volatile("" : "+v"(fl));        // (made here: hoisted to the kernel's entry, lane >> 2 and friends cost registers for the whole loop)
                 for (int base = 0; base < ndone; base += 16) {
-                    const int k = base + (lane >> 2), ch = lane & 3;
+                    const int k = base + (fl >> 2), ch = fl & 3;
                     if (k < ndone && ch < 3) {
                         const int sl = (int)map[k];
                         atomicAdd(ca->accum + (size_t)sl_pix[sl] * 4 + ch, sl_acc[sl * 3 + ch]);
