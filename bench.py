@@ -293,10 +293,12 @@ def main():
         # workload rendered with every counter on (rt_scene_counters; 1-3 % slower, outside the timed region): the ray
         # trees, and with them those counts, are identical from frame to frame.
         lean_rays = diag["rays"]
+        timed_clocks = {k: diag[k] for k in ("sum_wave_clk", "waves", "max_wave_clk")}     # wave clocks: of the last TIMED frame
         sc.counters(1)
         step(sc, cols, bufs, g)
         sc.status()
         assert diag["rays"] == lean_rays, (diag["rays"], lean_rays)
+        diag.update(timed_clocks)
         kern_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
         gather_ms = sum(e[2].elapsed_time(e[3]) for e in evs) / steps
         tt = torch.tensor([dt], dtype=torch.float64, device=gdev)
