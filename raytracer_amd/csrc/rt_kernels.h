@@ -669,11 +669,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BVH ? (RING 
             if (!alive) trav_cur = kBvhDone;
             auto backing = [&]() { return cold_args()->gstack + (size_t)blockIdx.x * (kBvhStack * 64) + lane; };
             // (the threshold is wave-uniform by construction, but arrives in a vector register, and the comparison with it
-            // makes the round loop a divergent loop for the compiler — exec-mask bookkeeping, the statistics in vector
-            // registers.  Handing it over through readfirstlane was measured per hand-out order: pixel-major 4K frames
-            // +0.7 %, the sample-major frames -0.9 % (mesh) and -1 % (1M spheres), which therefore keep the vector form.)
-            int ma = refill ? a.min_active : 0;
-            if (PHASE == 0) ma = __builtin_amdgcn_readfirstlane(ma);
+            // makes the round loop a divergent loop for the compiler — exec-mask bookkeeping, loop-carried scalars in vector
+            // registers.  Handed over through readfirstlane: 4K mixed frame +0.7 %; the sample-major frames lost 1 % to it
+            // while they carried the statistics through the loop, and gain 0.5 - 1 % since they do not, rt_scene_counters.)
+            const int ma = __builtin_amdgcn_readfirstlane(refill ? a.min_active : 0);
             closest_hit_bvh<RING, true, kBvhInnerMin, kBvhLeafMin, COUNT>(bvh, O, Dn, bvh_stack, 64, map + lane, backing, tcur, hidx, trav_cur, trav_sp, trav_lo,
                                             ma, n_nodes, n_prims, n_rin, n_rlf);
             busy = alive && trav_cur != kBvhDone;
