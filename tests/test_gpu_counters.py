@@ -17,14 +17,15 @@ def _mixed():
     return np.concatenate([base, scenes.heightfield_mesh(12, environment=False, base=-5.9, amplitude=1.0)])
 
 
-def _frame(s):
+def _frame(s, noalloc=False):
     import torch
     dev = torch.device("cuda", 0)
     rgba = torch.zeros((s.width, s.height, 4), dtype=torch.float32, device=dev)
     depth = torch.zeros((s.width, s.height), dtype=torch.float32, device=dev)
     ids = torch.zeros((s.width, s.height), dtype=torch.int64, device=dev)
     stats = torch.full((abi.RT_STATS_WORDS,), -1, dtype=torch.int64, device=dev)
-    s.renderColumnsDevice(rgba.data_ptr(), depth.data_ptr(), ids.data_ptr(), stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    render = s.renderColumnsDeviceNoAlloc if noalloc else s.renderColumnsDevice
+    render(rgba.data_ptr(), depth.data_ptr(), ids.data_ptr(), stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     s.status()
     return rgba.cpu().numpy(), depth.cpu().numpy(), ids.cpu().numpy(), [int(x) for x in stats.cpu().tolist()]
@@ -37,6 +38,10 @@ def test_frames_do_not_depend_on_the_counters(mesh, kw):
     lean = _frame(s)
     s.counters(1)
     full = _frame(s)
+    full_noalloc = _frame(s, noalloc=True)        # the entry point that allocates nothing runs the same instantiations
+    assert np.array_equal(full[0], full_noalloc[0])
+    for w in (0, 1, 3, 4, 5, 8, 9):            # (iterations and rounds depend on the number of waves, these do not)
+        assert full[3][w] == full_noalloc[3][w], w
     s.counters(0)
     again = _frame(s)
     for a, b in ((lean, full), (lean, again)):
