@@ -162,7 +162,7 @@ def parse_args(argv=None):
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--pool-blocks", type=int, default=0)
     ap.add_argument("--bvh-ring", type=int, default=0, help="tuning: 8 or 16 entries of the traversal stack in LDS (0 = by tree size)")
-    ap.add_argument("--bvh-min-active", type=int, default=0, help="tuning: refill threshold of the BVH kernels (0 = 28)")
+    ap.add_argument("--bvh-min-active", type=int, default=0, help="tuning: refill threshold of the BVH kernels (0 = 24, or 20 when 8 or more loose surfaces are scanned)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),

@@ -111,7 +111,7 @@ typedef struct rt_params {
     int32_t  estimator;           /* RT_ESTIMATOR_BRANCHING (0, the reference's renderScene) or RT_ESTIMATOR_SINGLE_PATH */
     int32_t  bvh_ring;            /* tuning/testing: traversal-stack entries kept in LDS, 0 = by tree size, 8 or 16
                                      (selects the kernel variant a BVH scene runs; results do not depend on it)   */
-    int32_t  bvh_min_active;      /* tuning/testing: lanes still walking below which a wave refills; 0 = 28, 1..64 */
+    int32_t  bvh_min_active;      /* tuning/testing: lanes still walking below which a wave refills; 0 = 24 (20 for scenes that scan 8 or more loose surfaces), 1..64 */
     int32_t  two_pass;            /* tuning/testing: 0 = frames of at most 2^19 pixel-samples are rendered in two passes
                                      (primaries, then their subtrees shared among all waves), 1 = always one pass;
                                      the image does not depend on it.  rt_render_device_noalloc renders such a frame in

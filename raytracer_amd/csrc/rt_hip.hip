@@ -229,7 +229,7 @@ struct Workspace {
 // refill threshold of the BVH kernels (lanes still walking); a wave needs a free sample slot to start a primary ray,
 // so the default must not exceed the sample slots of any variant (the kernel makes progress either way, see
 // trace_kernel "leave early", but a larger value only costs occupancy of the lanes)
-constexpr int kMinActiveDefault = 28;
+constexpr int kMinActiveDefault = 24;
 constexpr int kMinActiveManyLoose = 20;   // scenes that scan 8 or more loose surfaces per ray
 static_assert(kMinActiveDefault <= slots_of(true, 8) && kMinActiveDefault <= slots_of(true, 16), "refill threshold above the sample slots");
 
